@@ -1,0 +1,244 @@
+"""ctypes binding of librq_hip.so (C ABI declared in include/rq.h).
+
+This is the only place Python touches the native library.  There is no CPU fallback: if the shared
+object is missing or no gfx950 device is visible, construction of an index raises.
+
+Replaces the chromadb client calls of reference rag_uq/streaming_index.py:252-263,326-331,355-359,373.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+from typing import Optional, Tuple
+
+import numpy as np
+
+_PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = _PKG_DIR / "librq_hip.so"
+
+METRIC_COSINE = 0
+METRIC_IP = 1
+MAX_DIM = 768
+MAX_K = 1024
+
+
+class RqError(RuntimeError):
+    """A call into librq_hip.so failed; the message is rq_last_error()."""
+
+
+class rq_timing(C.Structure):
+    _fields_ = [
+        ("scan_ms", C.c_double),
+        ("scan_launches", C.c_int64),
+        ("scan_bytes", C.c_int64),
+        ("searches", C.c_int64),
+        ("queries", C.c_int64),
+        ("widened", C.c_int64),
+        ("exact_scans", C.c_int64),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/rq.h declares (tests check this)
+_SIGNATURES = {
+    "rq_device_count": (C.c_int, []),
+    "rq_index_create": (C.c_void_p, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "rq_index_destroy": (None, [C.c_void_p]),
+    "rq_index_dim": (C.c_int, [C.c_void_p]),
+    "rq_index_size": (C.c_int64, [C.c_void_p]),
+    "rq_index_set_row_offset": (C.c_int, [C.c_void_p, C.c_int64]),
+    "rq_index_reserve": (C.c_int, [C.c_void_p, C.c_int64]),
+    "rq_index_add_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "rq_index_add_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
+    "rq_index_add_f16_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "rq_index_add_f32_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
+    "rq_index_get_rows_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "rq_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "rq_search_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rq_search_fixup_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rq_merge_keys_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]),
+    "rq_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
+    "rq_get_option": (C.c_double, [C.c_void_p, C.c_char_p]),
+    "rq_get_timing": (C.c_int, [C.c_void_p, C.POINTER(rq_timing)]),
+    "rq_reset_timing": (C.c_int, [C.c_void_p]),
+    "rq_save": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "rq_load": (C.c_void_p, [C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
+    "rq_last_error": (C.c_char_p, []),
+    "rq_version": (C.c_char_p, []),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen librq_hip.so and declare every entry point.  Raises if the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # One HIP runtime per process: torch bundles its own libamdhip64.so.7 (same SONAME as /opt/rocm's).
+    # Whichever is loaded first serves both, a second copy cannot open the GPU -- so load torch's first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    if not LIB_PATH.exists():
+        raise RqError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C {(_PKG_DIR / 'csrc')}`; this backend has no CPU fallback"
+        )
+    lib = C.CDLL(str(LIB_PATH), mode=getattr(os, "RTLD_NOW", 2) | getattr(os, "RTLD_LOCAL", 0))
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load_library().rq_last_error().decode("utf-8", "replace")
+
+
+def _check(rc: int, what: str) -> int:
+    if rc < 0:
+        raise RqError(f"{what}: {last_error()} (code {rc})")
+    return rc
+
+
+def device_count() -> int:
+    return int(load_library().rq_device_count())
+
+
+def _ptr(a) -> C.c_void_p:
+    """Pointer of a numpy array, a torch tensor (host or device) or a raw integer address."""
+    if a is None:
+        return C.c_void_p(0)
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    if isinstance(a, np.ndarray):
+        return C.c_void_p(a.ctypes.data)
+    if hasattr(a, "data_ptr"):
+        return C.c_void_p(a.data_ptr())
+    raise TypeError(f"cannot take the address of {type(a)!r}")
+
+
+class NativeIndex:
+    """Thin owner of one rq_index handle (one row shard on one GPU)."""
+
+    def __init__(self, dim: int, device: int = 0, _handle: Optional[int] = None):
+        self._lib = load_library()
+        if _handle is None:
+            ids = (C.c_int * 1)(int(device))
+            _handle = self._lib.rq_index_create(int(dim), 1, ids)
+            if not _handle:
+                raise RqError(f"rq_index_create(dim={dim}, device={device}): {last_error()}")
+        self._h = C.c_void_p(_handle)
+        self.dim = int(self._lib.rq_index_dim(self._h))
+        self.device = int(device)
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.rq_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self) -> int:
+        return int(self._lib.rq_index_size(self._h))
+
+    # -- build ------------------------------------------------------------------------------
+    def reserve(self, n_rows: int) -> None:
+        _check(self._lib.rq_index_reserve(self._h, int(n_rows)), "rq_index_reserve")
+
+    def set_row_offset(self, off: int) -> None:
+        _check(self._lib.rq_index_set_row_offset(self._h, int(off)), "rq_index_set_row_offset")
+
+    def add_f16(self, rows: np.ndarray) -> None:
+        rows = np.ascontiguousarray(rows)
+        if rows.dtype == np.float16:
+            rows = rows.view(np.uint16)
+        if rows.dtype != np.uint16 or rows.ndim != 2 or rows.shape[1] != self.dim:
+            raise ValueError(f"expected [n][{self.dim}] float16/uint16 rows, got {rows.dtype} {rows.shape}")
+        _check(self._lib.rq_index_add_f16(self._h, _ptr(rows), rows.shape[0]), "rq_index_add_f16")
+
+    def add_f32(self, rows: np.ndarray, normalize: bool = True) -> None:
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        if rows.ndim != 2 or rows.shape[1] != self.dim:
+            raise ValueError(f"expected [n][{self.dim}] float32 rows, got {rows.shape}")
+        _check(self._lib.rq_index_add_f32(self._h, _ptr(rows), rows.shape[0], int(bool(normalize))), "rq_index_add_f32")
+
+    def add_f16_device(self, d_rows, n_rows: int) -> None:
+        _check(self._lib.rq_index_add_f16_device(self._h, _ptr(d_rows), int(n_rows)), "rq_index_add_f16_device")
+
+    def add_f32_device(self, d_rows, n_rows: int, normalize: bool = True) -> None:
+        _check(self._lib.rq_index_add_f32_device(self._h, _ptr(d_rows), int(n_rows), int(bool(normalize))),
+               "rq_index_add_f32_device")
+
+    def get_rows_f16(self, row_begin: int, n_rows: int) -> np.ndarray:
+        out = np.empty((int(n_rows), self.dim), dtype=np.uint16)
+        _check(self._lib.rq_index_get_rows_f16(self._h, int(row_begin), int(n_rows), _ptr(out)), "rq_index_get_rows_f16")
+        return out.view(np.float16)
+
+    # -- search -----------------------------------------------------------------------------
+    def search(self, queries: np.ndarray, k: int, metric: int = METRIC_COSINE) -> Tuple[np.ndarray, np.ndarray]:
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.ndim != 2 or q.shape[1] != self.dim:
+            raise ValueError(f"expected [B][{self.dim}] float32 queries, got {q.shape}")
+        B = q.shape[0]
+        scores = np.empty((B, int(k)), dtype=np.float32)
+        rows = np.empty((B, int(k)), dtype=np.int64)
+        _check(self._lib.rq_search(self._h, _ptr(q), B, int(k), int(metric), _ptr(scores), _ptr(rows)), "rq_search")
+        return scores, rows
+
+    def search_device(self, d_queries, B: int, k: int, metric: int, d_scores, d_rows, d_keys, d_status, stream: int = 0) -> None:
+        _check(self._lib.rq_search_device(self._h, _ptr(d_queries), int(B), int(k), int(metric), _ptr(d_scores), _ptr(d_rows),
+                                          _ptr(d_keys), _ptr(d_status), C.c_void_p(stream)), "rq_search_device")
+
+    def search_fixup_device(self, d_queries, B: int, k: int, metric: int, d_scores, d_rows, d_keys, d_status, stream: int = 0) -> int:
+        return _check(self._lib.rq_search_fixup_device(self._h, _ptr(d_queries), int(B), int(k), int(metric), _ptr(d_scores),
+                                                       _ptr(d_rows), _ptr(d_keys), _ptr(d_status), C.c_void_p(stream)),
+                      "rq_search_fixup_device")
+
+    # -- knobs / timing -----------------------------------------------------------------------
+    def set_option(self, name: str, value: float) -> None:
+        _check(self._lib.rq_set_option(self._h, name.encode(), float(value)), f"rq_set_option({name})")
+
+    def get_option(self, name: str) -> float:
+        return float(self._lib.rq_get_option(self._h, name.encode()))
+
+    def timing(self) -> dict:
+        t = rq_timing()
+        _check(self._lib.rq_get_timing(self._h, C.byref(t)), "rq_get_timing")
+        return {f: getattr(t, f) for f, _ in rq_timing._fields_}
+
+    def reset_timing(self) -> None:
+        _check(self._lib.rq_reset_timing(self._h), "rq_reset_timing")
+
+    # -- persistence ------------------------------------------------------------------------
+    def save(self, path: str) -> None:
+        _check(self._lib.rq_save(self._h, str(path).encode()), "rq_save")
+
+    @classmethod
+    def load(cls, path: str, device: int = 0) -> "NativeIndex":
+        lib = load_library()
+        ids = (C.c_int * 1)(int(device))
+        h = lib.rq_load(str(path).encode(), 1, ids)
+        if not h:
+            raise RqError(f"rq_load({path}): {last_error()}")
+        return cls(0, device, _handle=h)
+
+
+def merge_keys_device(d_keys_in, n_per_query: int, B: int, k: int, d_scores, d_rows, d_keys_out=None, stream: int = 0) -> None:
+    lib = load_library()
+    _check(lib.rq_merge_keys_device(_ptr(d_keys_in), int(n_per_query), int(B), int(k), _ptr(d_scores), _ptr(d_rows),
+                                    _ptr(d_keys_out), C.c_void_p(stream)), "rq_merge_keys_device")

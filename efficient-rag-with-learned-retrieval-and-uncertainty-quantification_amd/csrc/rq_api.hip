@@ -1,0 +1,621 @@
+// rq_api.hip -- the C ABI of include/rq.h: shard storage in HBM, search orchestration, persistence.
+//
+// One rq_index = one row shard resident on one MI355X.  Layout in HBM:
+//   x          [cap][768] fp16, cap % 64 == 0, rows >= n are zero      (the only large array)
+//   rownorm64  [cap]      fp64 L2 norm of the stored row               (exact re-score)
+//   inv_norm   [cap]      fp32 1/norm, 0 for zero rows and pad rows     (scan, cosine)
+//   ones       [cap]      fp32 1.0 for rows < n, 0 beyond              (scan, inner product; lazy)
+// plus one workspace per stream (query fragments, pooled bin maxima, bin keys, candidate keys).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/rq.h"
+#include "rq_device.h"
+#include "rq_kernels.h"
+
+hipError_t rq_rowscale_launch(const double* norm64, int64_t row_begin, int64_t row_end, float* inv_norm, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int set_err(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(expr)                                                                                    \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return set_err(RQ_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// index object
+// ---------------------------------------------------------------------------------------------
+struct Workspace {
+    int bcap = 0;                 // query slots (multiple of 64)
+    int64_t pooled_stride = 0;    // floats per query
+    int64_t binkeys_cap = 0;      // entries per query
+    int64_t cand_cap = 0;         // entries per query
+    _Float16* qh = nullptr;
+    float* q32 = nullptr;
+    double* qn = nullptr;
+    float* pooled = nullptr;
+    uint64_t* binkeys = nullptr;
+    uint64_t* cand = nullptr;
+    // staging for rq_search_fixup_device
+    int fix_bcap = 0, fix_k = 0;
+    float* fix_q = nullptr;
+    float* fix_scores = nullptr;
+    int64_t* fix_rows = nullptr;
+    uint64_t* fix_keys = nullptr;
+    int* fix_status = nullptr;
+};
+
+struct rq_index {
+    int dim = 0, device = 0, cu_count = 256;
+    int64_t n = 0, cap = 0, row_offset = 0;
+    char* x = nullptr;
+    double* rownorm64 = nullptr;
+    float* inv_norm = nullptr;
+    float* ones = nullptr;
+    int64_t ones_valid = 0;
+    double* d_maxnorm = nullptr;   // device scalar, bits of the running max row norm
+    double max_row_norm = 0.0;
+    // options
+    int ring = 4, prefetch = 1, bin_tiles = 4, wg_per_cu = 3, nt = -1, slack_bins = -1, profile = 0;
+    double eps = -1.0;
+    std::map<hipStream_t, Workspace> ws;
+    hipStream_t own_stream = nullptr;
+    // host-call staging
+    float* h_dq = nullptr; float* h_dscores = nullptr; int64_t* h_drows = nullptr; int* h_dstatus = nullptr;
+    int h_bcap = 0, h_kcap = 0;
+    // timing
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t ev_used = 0;
+    rq_timing t = {};
+};
+
+// Derived bound on |approximate scan score - exact score| for unit queries and cosine scaling:
+//   fp16 rounding of the unit query (2^-11 relative, 2^-25 absolute in the subnormal range),
+//   fp32 accumulation inside the MFMA chain (<= 4 * 768 * 2^-24 of sum|q_i x_i| <= 1, conservative),
+//   two fp32 roundings for the row scale.  See DESIGN.md "certificate".
+static const float RQ_EPS_DEFAULT = 7.0e-4f;
+
+static int nb_default(const rq_index* idx, int k) {
+    const int per_quad = 16 / idx->bin_tiles;
+    int slack = idx->slack_bins >= 0 ? idx->slack_bins : std::max(8, k / 4);
+    int nb = k + slack;
+    nb = (nb + per_quad - 1) / per_quad * per_quad;
+    return nb;
+}
+static const int RQ_NB_MAX = 3071;   // select kernel: m = nb + 1 <= RQ_SEL_L - RQ_SEL_THREADS
+
+static int use_device(const rq_index* idx) {
+    HIPCHK(hipSetDevice(idx->device));
+    return RQ_OK;
+}
+
+extern "C" int rq_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+extern "C" const char* rq_last_error(void) { return g_err; }
+extern "C" const char* rq_version(void) { return "rq-hip 0.1 (gfx950)"; }
+
+static int grow(rq_index* idx, int64_t want_rows) {
+    if (want_rows <= idx->cap) return RQ_OK;
+    int64_t cap = std::max<int64_t>(idx->cap * 2, 4096);
+    while (cap < want_rows) cap *= 2;
+    if (want_rows > (int64_t)1 << 27 && cap > want_rows + want_rows / 8) cap = want_rows + want_rows / 8;   // big shards: 12% headroom
+    cap = (cap + 63) / 64 * 64;
+    char* nx = nullptr; double* nn = nullptr; float* ni = nullptr;
+    hipError_t e = hipMalloc((void**)&nx, (size_t)cap * RQ_DPAD * 2);
+    if (e != hipSuccess) return set_err(RQ_ENOMEM, "hipMalloc of %lld corpus rows failed: %s", (long long)cap, hipGetErrorString(e));
+    HIPCHK(hipMalloc((void**)&nn, (size_t)cap * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&ni, (size_t)cap * sizeof(float)));
+    const int64_t keep = idx->n;
+    if (keep > 0) {
+        HIPCHK(hipMemcpyAsync(nx, idx->x, (size_t)keep * RQ_DPAD * 2, hipMemcpyDeviceToDevice, idx->own_stream));
+        HIPCHK(hipMemcpyAsync(nn, idx->rownorm64, (size_t)keep * sizeof(double), hipMemcpyDeviceToDevice, idx->own_stream));
+        HIPCHK(hipMemcpyAsync(ni, idx->inv_norm, (size_t)keep * sizeof(float), hipMemcpyDeviceToDevice, idx->own_stream));
+    }
+    HIPCHK(hipMemsetAsync(nx + (size_t)keep * RQ_DPAD * 2, 0, (size_t)(cap - keep) * RQ_DPAD * 2, idx->own_stream));
+    HIPCHK(hipMemsetAsync(nn + keep, 0, (size_t)(cap - keep) * sizeof(double), idx->own_stream));
+    HIPCHK(hipMemsetAsync(ni + keep, 0, (size_t)(cap - keep) * sizeof(float), idx->own_stream));
+    HIPCHK(hipStreamSynchronize(idx->own_stream));
+    if (idx->x) hipFree(idx->x);
+    if (idx->rownorm64) hipFree(idx->rownorm64);
+    if (idx->inv_norm) hipFree(idx->inv_norm);
+    if (idx->ones) { hipFree(idx->ones); idx->ones = nullptr; idx->ones_valid = 0; }
+    idx->x = nx; idx->rownorm64 = nn; idx->inv_norm = ni; idx->cap = cap;
+    return RQ_OK;
+}
+
+extern "C" rq_index* rq_index_create(int dim, int n_devices, const int* device_ids) {
+    if (dim < 1 || dim > RQ_MAX_DIM) { set_err(RQ_EINVAL, "dim %d outside 1..%d", dim, RQ_MAX_DIM); return nullptr; }
+    if (n_devices != 1 || !device_ids) {
+        set_err(RQ_EUNSUPPORTED, "n_devices must be 1 (one process per GPU; merge shards with rq_merge_keys_device)");
+        return nullptr;
+    }
+    const int ndev = rq_device_count();
+    if (ndev <= 0) { set_err(RQ_ENODEVICE, "no HIP device visible: the gfx950 backend has no CPU fallback"); return nullptr; }
+    if (device_ids[0] < 0 || device_ids[0] >= ndev) { set_err(RQ_EINVAL, "device %d outside 0..%d", device_ids[0], ndev - 1); return nullptr; }
+    rq_index* idx = new rq_index();
+    idx->dim = dim;
+    idx->device = device_ids[0];
+    hipDeviceProp_t prop;
+    if (hipSetDevice(idx->device) != hipSuccess || hipGetDeviceProperties(&prop, idx->device) != hipSuccess) {
+        set_err(RQ_EHIP, "cannot open device %d", idx->device);
+        delete idx;
+        return nullptr;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_err(RQ_ENODEVICE, "device %d is %s; this library holds gfx950 code only", idx->device, prop.gcnArchName);
+        delete idx;
+        return nullptr;
+    }
+    idx->cu_count = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&idx->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void**)&idx->d_maxnorm, sizeof(double)) != hipSuccess ||
+        hipMemset(idx->d_maxnorm, 0, sizeof(double)) != hipSuccess) {
+        set_err(RQ_EHIP, "device setup failed on device %d", idx->device);
+        delete idx;
+        return nullptr;
+    }
+    return idx;
+}
+
+static void free_ws(Workspace& w) {
+    void* p[] = {w.qh, w.q32, w.qn, w.pooled, w.binkeys, w.cand, w.fix_q, w.fix_scores, w.fix_rows, w.fix_keys, w.fix_status};
+    for (void* q : p) if (q) hipFree(q);
+    w = Workspace();
+}
+
+extern "C" void rq_index_destroy(rq_index* idx) {
+    if (!idx) return;
+    hipSetDevice(idx->device);
+    hipDeviceSynchronize();
+    for (auto& kv : idx->ws) free_ws(kv.second);
+    for (auto& ev : idx->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+    void* p[] = {idx->x, idx->rownorm64, idx->inv_norm, idx->ones, idx->d_maxnorm, idx->h_dq, idx->h_dscores, idx->h_drows, idx->h_dstatus};
+    for (void* q : p) if (q) hipFree(q);
+    if (idx->own_stream) hipStreamDestroy(idx->own_stream);
+    delete idx;
+}
+
+extern "C" int rq_index_dim(const rq_index* idx) { return idx ? idx->dim : RQ_EINVAL; }
+extern "C" int64_t rq_index_size(const rq_index* idx) { return idx ? idx->n : RQ_EINVAL; }
+extern "C" int rq_index_set_row_offset(rq_index* idx, int64_t off) {
+    if (!idx || off < 0) return set_err(RQ_EINVAL, "bad row offset");
+    idx->row_offset = off;
+    return RQ_OK;
+}
+extern "C" int rq_index_reserve(rq_index* idx, int64_t n_rows) {
+    if (!idx || n_rows < 0) return set_err(RQ_EINVAL, "bad reserve");
+    if (int r = use_device(idx)) return r;
+    return grow(idx, n_rows);
+}
+
+// ---- append ----------------------------------------------------------------------------------
+__global__ void rq_maxnorm_kernel(const double* norm64, int64_t b, int64_t e, unsigned long long* out) {
+    double m = 0.0;
+    for (int64_t i = b + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e; i += (int64_t)gridDim.x * blockDim.x) m = fmax(m, norm64[i]);
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(m));   // non-negative doubles order as integers
+}
+
+static int finish_add(rq_index* idx, int64_t n_new) {
+    hipStream_t s = idx->own_stream;
+    const int64_t b = idx->n, e = idx->n + n_new;
+    HIPCHK(rq_rownorm_launch(idx->x, b, e, idx->rownorm64, s));
+    HIPCHK(rq_rowscale_launch(idx->rownorm64, b, e, idx->inv_norm, s));
+    hipLaunchKernelGGL(rq_maxnorm_kernel, dim3(256), dim3(256), 0, s, (const double*)idx->rownorm64, b, e, (unsigned long long*)idx->d_maxnorm);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&idx->max_row_norm, idx->d_maxnorm, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    idx->n = e;
+    if ((uint64_t)(idx->row_offset + idx->n) >= 0xffffffffull) return set_err(RQ_EUNSUPPORTED, "row ids beyond 2^32-1 are not supported");
+    return RQ_OK;
+}
+
+static int add_device_common(rq_index* idx, const void* d_rows, int64_t n_rows, bool is_f32, int normalize) {
+    if (!idx || (!d_rows && n_rows > 0) || n_rows < 0) return set_err(RQ_EINVAL, "bad add arguments");
+    if (n_rows == 0) return RQ_OK;
+    if (int r = use_device(idx)) return r;
+    if (int r = grow(idx, idx->n + n_rows)) return r;
+    char* dst = idx->x + (size_t)idx->n * RQ_DPAD * 2;
+    if (is_f32) HIPCHK(rq_convert_f32_launch((const float*)d_rows, idx->dim, n_rows, normalize, dst, idx->own_stream));
+    else if (idx->dim == RQ_DPAD) HIPCHK(hipMemcpyAsync(dst, d_rows, (size_t)n_rows * RQ_DPAD * 2, hipMemcpyDeviceToDevice, idx->own_stream));
+    else HIPCHK(rq_pad_f16_launch(d_rows, idx->dim, n_rows, dst, idx->own_stream));
+    return finish_add(idx, n_rows);
+}
+extern "C" int rq_index_add_f16_device(rq_index* idx, const void* d_rows, int64_t n_rows) { return add_device_common(idx, d_rows, n_rows, false, 0); }
+extern "C" int rq_index_add_f32_device(rq_index* idx, const float* d_rows, int64_t n_rows, int normalize) {
+    return add_device_common(idx, d_rows, n_rows, true, normalize);
+}
+
+static int add_host_common(rq_index* idx, const void* rows, int64_t n_rows, bool is_f32, int normalize) {
+    if (!idx || (!rows && n_rows > 0) || n_rows < 0) return set_err(RQ_EINVAL, "bad add arguments");
+    if (n_rows == 0) return RQ_OK;
+    if (int r = use_device(idx)) return r;
+    if (int r = grow(idx, idx->n + n_rows)) return r;
+    // stream the host rows through a bounded device staging buffer
+    const size_t esz = is_f32 ? 4 : 2;
+    const int64_t chunk = std::max<int64_t>(1, ((int64_t)256 << 20) / (int64_t)(idx->dim * esz));
+    void* stage = nullptr;
+    HIPCHK(hipMalloc(&stage, (size_t)std::min(chunk, n_rows) * idx->dim * esz));
+    int rc = RQ_OK;
+    for (int64_t off = 0; off < n_rows && rc == RQ_OK; off += chunk) {
+        const int64_t m = std::min(chunk, n_rows - off);
+        hipError_t e = hipMemcpy(stage, (const char*)rows + (size_t)off * idx->dim * esz, (size_t)m * idx->dim * esz, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { rc = set_err(RQ_EHIP, "H2D copy failed: %s", hipGetErrorString(e)); break; }
+        rc = add_device_common(idx, stage, m, is_f32, normalize);
+    }
+    hipFree(stage);
+    return rc;
+}
+extern "C" int rq_index_add_f16(rq_index* idx, const uint16_t* rows, int64_t n_rows) { return add_host_common(idx, rows, n_rows, false, 0); }
+extern "C" int rq_index_add_f32(rq_index* idx, const float* rows, int64_t n_rows, int normalize) {
+    return add_host_common(idx, rows, n_rows, true, normalize);
+}
+
+extern "C" int rq_index_get_rows_f16(const rq_index* idx, int64_t row_begin, int64_t n_rows, uint16_t* out) {
+    if (!idx || !out || row_begin < 0 || n_rows < 0 || row_begin + n_rows > idx->n) return set_err(RQ_EINVAL, "row range outside the index");
+    if (n_rows == 0) return RQ_OK;
+    if (int r = use_device(idx)) return r;
+    HIPCHK(hipMemcpy2D(out, (size_t)idx->dim * 2, idx->x + (size_t)row_begin * RQ_DPAD * 2, (size_t)RQ_DPAD * 2, (size_t)idx->dim * 2,
+                       (size_t)n_rows, hipMemcpyDeviceToHost));
+    return RQ_OK;
+}
+
+// ---- options ---------------------------------------------------------------------------------
+extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
+    if (!idx || !name) return set_err(RQ_EINVAL, "bad option call");
+    const std::string s(name);
+    if (s == "ring") { if (v < 3 || v > 6) return set_err(RQ_EINVAL, "ring must be 3..6"); idx->ring = (int)v; }
+    else if (s == "prefetch") { if (v != 1 && v != 4 && v != 6 && v != 12) return set_err(RQ_EINVAL, "prefetch must be 1, 4, 6 or 12"); idx->prefetch = (int)v; }
+    else if (s == "bin_tiles") { if (v != 1 && v != 2 && v != 4) return set_err(RQ_EINVAL, "bin_tiles must be 1, 2 or 4"); idx->bin_tiles = (int)v; }
+    else if (s == "wg_per_cu") { if (v < 1 || v > 8) return set_err(RQ_EINVAL, "wg_per_cu must be 1..8"); idx->wg_per_cu = (int)v; }
+    else if (s == "nt") idx->nt = (int)v;
+    else if (s == "slack_bins") idx->slack_bins = (int)v;
+    else if (s == "eps") idx->eps = v;
+    else if (s == "profile") idx->profile = (int)v;
+    else return set_err(RQ_EINVAL, "unknown option '%s'", name);
+    return RQ_OK;
+}
+extern "C" double rq_get_option(const rq_index* idx, const char* name) {
+    if (!idx || !name) return NAN;
+    const std::string s(name);
+    if (s == "ring") return idx->ring;
+    if (s == "prefetch") return idx->prefetch;
+    if (s == "bin_tiles") return idx->bin_tiles;
+    if (s == "wg_per_cu") return idx->wg_per_cu;
+    if (s == "nt") return idx->nt;
+    if (s == "slack_bins") return idx->slack_bins;
+    if (s == "eps") return idx->eps < 0 ? RQ_EPS_DEFAULT : idx->eps;
+    if (s == "profile") return idx->profile;
+    if (s == "cu_count") return idx->cu_count;
+    if (s == "max_row_norm") return idx->max_row_norm;
+    return NAN;
+}
+
+// ---- search ----------------------------------------------------------------------------------
+template <class T>
+static int ensure(T*& p, size_t have_elems, size_t want_elems) {
+    if (p && have_elems >= want_elems) return RQ_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    hipError_t e = hipMalloc((void**)&p, want_elems * sizeof(T));
+    if (e != hipSuccess) return set_err(RQ_ENOMEM, "workspace hipMalloc of %zu bytes failed: %s", want_elems * sizeof(T), hipGetErrorString(e));
+    return RQ_OK;
+}
+
+static int ensure_ws(rq_index* idx, Workspace& w, int bpad, int64_t stride, int64_t m, int64_t ncand) {
+    const bool regrow_b = bpad > w.bcap;
+    const int bcap = std::max(bpad, w.bcap);
+    if (regrow_b) {
+        if (int r = ensure(w.qh, 0, (size_t)bcap * RQ_DPAD)) return r;
+        if (int r = ensure(w.q32, 0, (size_t)bcap * RQ_DPAD)) return r;
+        if (int r = ensure(w.qn, 0, (size_t)bcap)) return r;
+    }
+    if (regrow_b || stride > w.pooled_stride) {
+        const int64_t st = std::max(stride, w.pooled_stride);
+        if (int r = ensure(w.pooled, 0, (size_t)bcap * st)) return r;
+        w.pooled_stride = st;
+    }
+    if (regrow_b || m > w.binkeys_cap) {
+        const int64_t mm = std::max(m, w.binkeys_cap);
+        if (int r = ensure(w.binkeys, 0, (size_t)bcap * mm)) return r;
+        w.binkeys_cap = mm;
+    }
+    if (regrow_b || ncand > w.cand_cap) {
+        const int64_t nc = std::max(ncand, w.cand_cap);
+        if (int r = ensure(w.cand, 0, (size_t)bcap * nc)) return r;
+        w.cand_cap = nc;
+    }
+    w.bcap = bcap;
+    return RQ_OK;
+}
+
+static int ensure_ones(rq_index* idx, hipStream_t s) {
+    if (idx->ones && idx->ones_valid == idx->n) return RQ_OK;
+    if (!idx->ones) HIPCHK(hipMalloc((void**)&idx->ones, (size_t)idx->cap * sizeof(float)));
+    std::vector<float> h((size_t)idx->cap, 0.f);
+    std::fill(h.begin(), h.begin() + idx->n, 1.f);
+    HIPCHK(hipMemcpy(idx->ones, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    idx->ones_valid = idx->n;
+    return RQ_OK;
+}
+
+static int fill_empty(int B, int k, float* d_scores, int64_t* d_rows, uint64_t* d_keys, int* d_status, hipStream_t s) {
+    HIPCHK(hipMemsetAsync(d_scores, 0, (size_t)B * k * sizeof(float), s));
+    HIPCHK(hipMemsetAsync(d_rows, 0xff, (size_t)B * k * sizeof(int64_t), s));
+    if (d_keys) HIPCHK(hipMemsetAsync(d_keys, 0, (size_t)B * k * sizeof(uint64_t), s));
+    HIPCHK(hipMemsetAsync(d_status, 0, (size_t)B * sizeof(int), s));
+    return RQ_OK;
+}
+
+// One pass of the pipeline for B queries.  nb < 0: exact scan (every bin re-scored, no corpus scan).
+static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metric, int nb, float* d_scores, int64_t* d_rows,
+                        uint64_t* d_keys, int* d_status, hipStream_t s) {
+    if (idx->n == 0) return fill_empty(B, k, d_scores, d_rows, d_keys, d_status, s);
+    const int R = idx->bin_tiles, per_quad = 16 / R, binrows = 4 * R;
+    const int nquads = (int)((idx->n + 63) / 64);
+    const int64_t nbins = (int64_t)nquads * per_quad;
+    const bool exact = nb < 0 || nb >= nbins;
+    if (exact) nb = (int)std::min<int64_t>(nbins, INT32_MAX / 64);
+    if (!exact && nb > RQ_NB_MAX) return set_err(RQ_EINVAL, "nb %d too large", nb);
+    const int bpad = (B + 63) / 64 * 64;
+    const int64_t stride = (nbins + 63) / 64 * 64;
+    const int m = nb + 1;
+    const int64_t ncand = (int64_t)nb * binrows;
+    Workspace& w = idx->ws[s];
+    if (int r = ensure_ws(idx, w, bpad, exact ? 64 : stride, exact ? 1 : m, ncand)) return r;
+    const float* scale = idx->inv_norm;
+    if (metric == RQ_METRIC_IP) { if (int r = ensure_ones(idx, s)) return r; scale = idx->ones; }
+
+    HIPCHK(rq_prep_queries_launch(d_q, idx->dim, B, bpad, w.qh, w.q32, w.qn, s));
+    if (!exact) {
+        const bool nt = idx->nt < 0 ? (idx->n * (int64_t)(RQ_DPAD * 2) > ((int64_t)160 << 20)) : idx->nt != 0;
+        const int grid = (int)std::min<int64_t>(nquads, (int64_t)idx->cu_count * idx->wg_per_cu);
+        for (int blk = 0; blk < bpad / 64; ++blk) {
+            RqScanArgs a;
+            a.x = idx->x;
+            a.row_scale = scale;
+            a.qh = w.qh + (size_t)blk * 64 * RQ_DPAD;
+            a.pooled = w.pooled + (size_t)blk * 64 * w.pooled_stride;
+            a.pooled_stride = w.pooled_stride;
+            a.n_rows = idx->n;
+            a.nquads = nquads;
+            a.nq_valid = std::min(64, B - blk * 64);
+            const bool prof = idx->profile && idx->ev_used < 16384;
+            if (prof) {
+                if (idx->ev_used == idx->events.size()) {
+                    hipEvent_t e0, e1;
+                    HIPCHK(hipEventCreate(&e0));
+                    HIPCHK(hipEventCreate(&e1));
+                    idx->events.push_back({e0, e1});
+                }
+                HIPCHK(hipEventRecord(idx->events[idx->ev_used].first, s));
+            }
+            HIPCHK(rq_scan_launch(a, idx->ring, idx->prefetch, R, nt, grid, s));
+            if (prof) { HIPCHK(hipEventRecord(idx->events[idx->ev_used].second, s)); idx->ev_used++; }
+        }
+        HIPCHK(rq_select_bins_launch(w.pooled, w.pooled_stride, nbins, B, m, w.binkeys, s));
+    }
+    RqRescoreArgs ra;
+    ra.x = idx->x; ra.q32 = w.q32; ra.qnorm64 = w.qn; ra.rownorm64 = idx->rownorm64;
+    ra.binkeys = exact ? nullptr : w.binkeys; ra.binkeys_stride = m; ra.nb = nb; ra.R = R; ra.metric = metric;
+    ra.n_rows = idx->n; ra.cand = w.cand;
+    HIPCHK(rq_rescore_launch(ra, B, s));
+    RqFinalArgs fa;
+    fa.cand = w.cand; fa.ncand = (int)ncand; fa.binkeys = w.binkeys; fa.binkeys_stride = m; fa.nb = nb; fa.nbins = exact ? nb : nbins;
+    fa.qnorm64 = w.qn; fa.metric = metric; fa.eps = idx->eps < 0 ? RQ_EPS_DEFAULT : (float)idx->eps;
+    fa.max_row_norm = (float)(idx->max_row_norm * (1.0 + 1e-6)); fa.k = k; fa.row_offset = idx->row_offset; fa.n_rows = idx->n;
+    fa.out_scores = d_scores; fa.out_rows = d_rows; fa.out_keys = d_keys; fa.out_status = d_status;
+    HIPCHK(rq_final_launch(fa, B, s));
+    return RQ_OK;
+}
+
+static int check_search_args(const rq_index* idx, const void* q, int B, int k, int metric, const void* sc, const void* rows) {
+    if (!idx || !q || !sc || !rows) return set_err(RQ_EINVAL, "null argument");
+    if (B < 1 || B > 65535) return set_err(RQ_EINVAL, "B %d outside 1..65535", B);
+    if (k < 1 || k > RQ_MAX_K) return set_err(RQ_EINVAL, "k %d outside 1..%d", k, RQ_MAX_K);
+    if (metric != RQ_METRIC_COSINE && metric != RQ_METRIC_IP) return set_err(RQ_EINVAL, "unknown metric %d", metric);
+    return RQ_OK;
+}
+
+extern "C" int rq_search_device(rq_index* idx, const float* d_queries, int B, int k, int metric, float* d_scores, int64_t* d_rows,
+                                uint64_t* d_keys, int* d_status, void* stream) {
+    if (int r = check_search_args(idx, d_queries, B, k, metric, d_scores, d_rows)) return r;
+    if (!d_status) return set_err(RQ_EINVAL, "d_status is required");
+    if (int r = use_device(idx)) return r;
+    idx->t.searches++;
+    idx->t.queries += B;
+    return run_pipeline(idx, d_queries, B, k, metric, nb_default(idx, k), d_scores, d_rows, d_keys, d_status, (hipStream_t)stream);
+}
+
+extern "C" int rq_search_fixup_device(rq_index* idx, const float* d_queries, int B, int k, int metric, float* d_scores,
+                                      int64_t* d_rows, uint64_t* d_keys, int* d_status, void* stream) {
+    if (int r = check_search_args(idx, d_queries, B, k, metric, d_scores, d_rows)) return r;
+    if (!d_status) return set_err(RQ_EINVAL, "d_status is required");
+    if (int r = use_device(idx)) return r;
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<int> st((size_t)B);
+    HIPCHK(hipMemcpyAsync(st.data(), d_status, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    std::vector<int> bad;
+    for (int q = 0; q < B; ++q) if (st[q] != 0) bad.push_back(q);
+    if (bad.empty()) return 0;
+    const int repaired = (int)bad.size();
+    Workspace& w = idx->ws[s];
+    const int fb = (int)bad.size();
+    if (fb > w.fix_bcap || k > w.fix_k) {
+        const int nb_ = std::max(fb, w.fix_bcap), nk = std::max(k, w.fix_k);
+        if (int r = ensure(w.fix_q, 0, (size_t)nb_ * RQ_MAX_DIM)) return r;
+        if (int r = ensure(w.fix_scores, 0, (size_t)nb_ * nk)) return r;
+        if (int r = ensure(w.fix_rows, 0, (size_t)nb_ * nk)) return r;
+        if (int r = ensure(w.fix_keys, 0, (size_t)nb_ * nk)) return r;
+        if (int r = ensure(w.fix_status, 0, (size_t)nb_)) return r;
+        w.fix_bcap = nb_; w.fix_k = nk;
+    }
+    // ladder: 4x wider candidate set, then the full fp64 scan
+    const int nb1 = std::min(RQ_NB_MAX, 4 * nb_default(idx, k));
+    for (int level = 0; level < 2 && !bad.empty(); ++level) {
+        const int nbq = (int)bad.size();
+        for (int i = 0; i < nbq; ++i)
+            HIPCHK(hipMemcpyAsync(w.fix_q + (size_t)i * idx->dim, d_queries + (size_t)bad[i] * idx->dim, (size_t)idx->dim * sizeof(float),
+                                  hipMemcpyDeviceToDevice, s));
+        if (level == 0) {
+            idx->t.widened += nbq;
+            if (int r = run_pipeline(idx, w.fix_q, nbq, k, metric, nb1, w.fix_scores, w.fix_rows, w.fix_keys, w.fix_status, s)) return r;
+        } else {
+            idx->t.exact_scans += nbq;
+            // bound the candidate memory: a few queries per exact pass
+            const int64_t per_q = ((idx->n + 63) / 64) * 64 * (int64_t)sizeof(uint64_t);
+            const int group = (int)std::max<int64_t>(1, std::min<int64_t>(nbq, ((int64_t)1 << 30) / std::max<int64_t>(per_q, 1)));
+            for (int off = 0; off < nbq; off += group) {
+                const int g = std::min(group, nbq - off);
+                if (int r = run_pipeline(idx, w.fix_q + (size_t)off * idx->dim, g, k, metric, -1, w.fix_scores + (size_t)off * k,
+                                         w.fix_rows + (size_t)off * k, w.fix_keys + (size_t)off * k, w.fix_status + off, s))
+                    return r;
+            }
+        }
+        std::vector<int> st2((size_t)nbq);
+        HIPCHK(hipMemcpyAsync(st2.data(), w.fix_status, (size_t)nbq * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        std::vector<int> still;
+        for (int i = 0; i < nbq; ++i) {
+            if (st2[i] == 0) {
+                const int q = bad[i];
+                HIPCHK(hipMemcpyAsync(d_scores + (size_t)q * k, w.fix_scores + (size_t)i * k, (size_t)k * sizeof(float), hipMemcpyDeviceToDevice, s));
+                HIPCHK(hipMemcpyAsync(d_rows + (size_t)q * k, w.fix_rows + (size_t)i * k, (size_t)k * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+                if (d_keys) HIPCHK(hipMemcpyAsync(d_keys + (size_t)q * k, w.fix_keys + (size_t)i * k, (size_t)k * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
+                HIPCHK(hipMemsetAsync(d_status + q, 0, sizeof(int), s));
+            } else {
+                still.push_back(bad[i]);
+            }
+        }
+        HIPCHK(hipStreamSynchronize(s));
+        bad.swap(still);
+    }
+    if (!bad.empty()) return set_err(RQ_EHIP, "internal: %zu queries uncertified after the exact scan", bad.size());
+    return repaired;
+}
+
+extern "C" int rq_search(rq_index* idx, const float* queries, int B, int k, int metric, float* out_scores, int64_t* out_rows) {
+    if (int r = check_search_args(idx, queries, B, k, metric, out_scores, out_rows)) return r;
+    if (int r = use_device(idx)) return r;
+    if (B > idx->h_bcap || k > idx->h_kcap) {
+        const int nb = std::max(B, idx->h_bcap), nk = std::max(k, idx->h_kcap);
+        if (int r = ensure(idx->h_dq, 0, (size_t)nb * RQ_MAX_DIM)) return r;
+        if (int r = ensure(idx->h_dscores, 0, (size_t)nb * nk)) return r;
+        if (int r = ensure(idx->h_drows, 0, (size_t)nb * nk)) return r;
+        if (int r = ensure(idx->h_dstatus, 0, (size_t)nb)) return r;
+        idx->h_bcap = nb; idx->h_kcap = nk;
+    }
+    hipStream_t s = idx->own_stream;
+    HIPCHK(hipMemcpyAsync(idx->h_dq, queries, (size_t)B * idx->dim * sizeof(float), hipMemcpyHostToDevice, s));
+    if (int r = rq_search_device(idx, idx->h_dq, B, k, metric, idx->h_dscores, idx->h_drows, nullptr, idx->h_dstatus, s)) return r;
+    const int fr = rq_search_fixup_device(idx, idx->h_dq, B, k, metric, idx->h_dscores, idx->h_drows, nullptr, idx->h_dstatus, s);
+    if (fr < 0) return fr;
+    HIPCHK(hipMemcpyAsync(out_scores, idx->h_dscores, (size_t)B * k * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out_rows, idx->h_drows, (size_t)B * k * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return RQ_OK;
+}
+
+extern "C" int rq_merge_keys_device(const uint64_t* d_keys_in, int n_per_query, int B, int k, float* d_scores, int64_t* d_rows,
+                                    uint64_t* d_keys_out, void* stream) {
+    if (!d_keys_in || !d_scores || !d_rows || B < 1 || k < 1 || k > RQ_MAX_K || n_per_query < 0) return set_err(RQ_EINVAL, "bad merge arguments");
+    HIPCHK(rq_merge_keys_launch(d_keys_in, n_per_query, B, k, d_scores, d_rows, d_keys_out, (hipStream_t)stream));
+    return RQ_OK;
+}
+
+// ---- timing ----------------------------------------------------------------------------------
+extern "C" int rq_get_timing(rq_index* idx, rq_timing* out) {
+    if (!idx || !out) return set_err(RQ_EINVAL, "null argument");
+    if (int r = use_device(idx)) return r;
+    HIPCHK(hipDeviceSynchronize());
+    double ms = 0.0;
+    for (size_t i = 0; i < idx->ev_used; ++i) {
+        float t = 0.f;
+        HIPCHK(hipEventElapsedTime(&t, idx->events[i].first, idx->events[i].second));
+        ms += t;
+    }
+    idx->t.scan_ms = ms;
+    idx->t.scan_launches = (int64_t)idx->ev_used;
+    idx->t.scan_bytes = (int64_t)idx->ev_used * idx->n * (int64_t)(RQ_DPAD * 2);
+    *out = idx->t;
+    return RQ_OK;
+}
+extern "C" int rq_reset_timing(rq_index* idx) {
+    if (!idx) return set_err(RQ_EINVAL, "null argument");
+    if (int r = use_device(idx)) return r;
+    HIPCHK(hipDeviceSynchronize());
+    idx->ev_used = 0;
+    idx->t = rq_timing{};
+    return RQ_OK;
+}
+
+// ---- persistence -----------------------------------------------------------------------------
+extern "C" int rq_save(const rq_index* idx, const char* path) {
+    if (!idx || !path) return set_err(RQ_EINVAL, "null argument");
+    if (int r = use_device(idx)) return r;
+    const std::string meta = std::string(path) + ".meta", data = std::string(path) + ".f16";
+    FILE* f = fopen(data.c_str(), "wb");
+    if (!f) return set_err(RQ_EIO, "cannot write %s", data.c_str());
+    const int64_t chunk = 65536;
+    std::vector<uint16_t> buf((size_t)chunk * idx->dim);
+    for (int64_t off = 0; off < idx->n; off += chunk) {
+        const int64_t m = std::min(chunk, idx->n - off);
+        if (int r = rq_index_get_rows_f16(idx, off, m, buf.data())) { fclose(f); return r; }
+        if (fwrite(buf.data(), (size_t)idx->dim * 2, (size_t)m, f) != (size_t)m) { fclose(f); return set_err(RQ_EIO, "short write to %s", data.c_str()); }
+    }
+    fclose(f);
+    f = fopen(meta.c_str(), "w");
+    if (!f) return set_err(RQ_EIO, "cannot write %s", meta.c_str());
+    fprintf(f, "rq-index 1\ndim %d\nrows %lld\ndtype f16\n", idx->dim, (long long)idx->n);
+    fclose(f);
+    return RQ_OK;
+}
+
+extern "C" rq_index* rq_load(const char* path, int n_devices, const int* device_ids) {
+    if (!path) { set_err(RQ_EINVAL, "null path"); return nullptr; }
+    const std::string meta = std::string(path) + ".meta", data = std::string(path) + ".f16";
+    FILE* f = fopen(meta.c_str(), "r");
+    if (!f) { set_err(RQ_EIO, "cannot read %s", meta.c_str()); return nullptr; }
+    int ver = 0, dim = 0;
+    long long rows = -1;
+    char dtype[16] = "";
+    const int got = fscanf(f, "rq-index %d dim %d rows %lld dtype %15s", &ver, &dim, &rows, dtype);
+    fclose(f);
+    if (got != 4 || ver != 1 || rows < 0 || strcmp(dtype, "f16") != 0) { set_err(RQ_EIO, "%s is not an rq-index v1 meta file", meta.c_str()); return nullptr; }
+    rq_index* idx = rq_index_create(dim, n_devices, device_ids);
+    if (!idx) return nullptr;
+    f = fopen(data.c_str(), "rb");
+    if (!f) { set_err(RQ_EIO, "cannot read %s", data.c_str()); rq_index_destroy(idx); return nullptr; }
+    if (rows > 0 && rq_index_reserve(idx, rows) != RQ_OK) { fclose(f); rq_index_destroy(idx); return nullptr; }
+    const int64_t chunk = 65536;
+    std::vector<uint16_t> buf((size_t)chunk * dim);
+    for (int64_t off = 0; off < rows; off += chunk) {
+        const int64_t m = std::min<int64_t>(chunk, rows - off);
+        if (fread(buf.data(), (size_t)dim * 2, (size_t)m, f) != (size_t)m) { fclose(f); set_err(RQ_EIO, "short read from %s", data.c_str()); rq_index_destroy(idx); return nullptr; }
+        if (rq_index_add_f16(idx, buf.data(), m) != RQ_OK) { fclose(f); rq_index_destroy(idx); return nullptr; }
+    }
+    fclose(f);
+    return idx;
+}

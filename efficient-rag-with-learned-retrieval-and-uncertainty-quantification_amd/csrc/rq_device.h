@@ -1,0 +1,54 @@
+// rq_device.h -- shared device-side helpers for the dense-retrieval hot path (gfx950 only).
+//
+// Replaces the arithmetic the reference delegates to ChromaDB's cosine kNN
+// (reference rag_uq/streaming_index.py:355-368, collection.query + `1 - distance`).
+//
+// Vocabulary
+//   row      one passage vector of the corpus (fp16, DPAD elements, zero padded)
+//   quad     64 consecutive rows = 4 tiles of 16 rows; the scan kernel's work unit
+//   bin      4*R rows of one quad whose maximum approximate score the scan kernel keeps
+//   key      64-bit sortable (score, index) pair: larger key = better rank
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RQ_DPAD 768            // padded row length the kernels are specialised for
+#define RQ_QBLOCK 64           // queries scored per corpus pass
+#define RQ_QUAD_ROWS 64
+#define RQ_TILE_ROWS 16
+
+typedef _Float16 rq_half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 rq_half4 __attribute__((ext_vector_type(4)));
+typedef float rq_float4 __attribute__((ext_vector_type(4)));
+
+// Order-preserving map float -> uint32 (larger float = larger uint). NaN must be removed first.
+__host__ __device__ static inline uint32_t rq_mono32(float f) {
+    uint32_t u;
+    __builtin_memcpy(&u, &f, 4);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ static inline float rq_unmono32(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+// key = (mono(score) << 32) | (0xffffffff - index): sorts by score desc, then index asc.
+// key 0 is reserved for "empty".
+__host__ __device__ static inline uint64_t rq_make_key(float score, uint32_t index) {
+    return ((uint64_t)rq_mono32(score) << 32) | (uint64_t)(0xffffffffu - index);
+}
+__host__ __device__ static inline float rq_key_score(uint64_t key) { return rq_unmono32((uint32_t)(key >> 32)); }
+__host__ __device__ static inline uint32_t rq_key_index(uint64_t key) { return 0xffffffffu - (uint32_t)(key & 0xffffffffu); }
+
+// Rows of bin `bin` for bins of 4*R rows (see rq_scan.hip for why bins look like this):
+//   per_quad = 16 / R bins per quad; inside a quad bin = kg * (4/R) + u,
+//   rows = quad*64 + 16*(u*R + tt) + 4*kg + i   for tt < R, i < 4.
+__host__ __device__ static inline int64_t rq_bin_row(int64_t bin, int R, int j /* 0 .. 4R-1 */) {
+    const int per_quad = 16 / R, per_kg = 4 / R;
+    const int64_t quad = bin / per_quad;
+    const int rem = (int)(bin % per_quad);
+    const int kg = rem / per_kg, u = rem % per_kg;
+    const int tt = j >> 2, i = j & 3;
+    return quad * 64 + 16 * (u * R + tt) + 4 * kg + i;
+}

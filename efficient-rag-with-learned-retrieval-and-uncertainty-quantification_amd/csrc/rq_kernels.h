@@ -1,0 +1,75 @@
+// rq_kernels.h -- host-visible launchers of the HIP kernels (internal; the public C ABI is include/rq.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct RqScanArgs {
+    const void* x;            // fp16 corpus shard [rows_padded][768], rows_padded % 64 == 0, pad rows zero
+    const float* row_scale;   // [rows_padded] 1/||row|| (cosine) or 1.0 (inner product); pad entries 0
+    const _Float16* qh;       // [64][768] unit-norm fp16 queries of this block, unused slots zero
+    float* pooled;            // [64][pooled_stride] per-bin maxima of the approximate score
+    int64_t pooled_stride;    // floats per query row, >= nquads * 16 / R
+    int64_t n_rows;           // valid rows of the shard
+    int nquads;               // ceil(n_rows / 64)
+    int nq_valid;             // queries of this block that are real (<= 64)
+};
+
+hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int R, bool nt, int grid, hipStream_t stream);
+size_t rq_scan_lds_bytes(int S);
+
+// Row statistics at add time: row_norm64[i] = sqrt(sum x^2) in fp64, row_scale[i] = (float)(1/norm) or 0.
+hipError_t rq_rownorm_launch(const void* x, int64_t row_begin, int64_t row_end, double* norm64, hipStream_t stream);
+
+// fp32 rows (device) -> fp16 rows, optionally L2-normalised first (see include/rq.h rq_index_add_f32).
+hipError_t rq_convert_f32_launch(const float* src, int dim, int64_t n, int normalize, void* dst_rows_f16, hipStream_t stream);
+hipError_t rq_pad_f16_launch(const void* src, int dim, int64_t n, void* dst_rows_f16, hipStream_t stream);
+
+// Query preparation: qnorm64[q] = ||q|| (fp64); qh = fp16(q/||q||) padded to 768, slots >= B zero.
+hipError_t rq_prep_queries_launch(const float* q, int dim, int B, int Bpad, _Float16* qh, float* q32pad, double* qnorm64,
+                                  hipStream_t stream);
+
+// Pass 2: per query, the m best bins of pooled[q][0..nbins) as sorted keys (score desc, bin asc); 0-padded.
+hipError_t rq_select_bins_launch(const float* pooled, int64_t pooled_stride, int64_t nbins, int B, int m,
+                                 uint64_t* binkeys, hipStream_t stream);
+
+// Pass 3: exact fp64 re-score of every row of the first nb bins of each query -> candidate keys (score, local row).
+struct RqRescoreArgs {
+    const void* x;
+    const float* q32;          // [B][768] raw fp32 queries, zero padded
+    const double* qnorm64;     // [B]
+    const double* rownorm64;   // [rows_padded]
+    const uint64_t* binkeys;   // [B][binkeys_stride]
+    int binkeys_stride;
+    int nb;                    // bins re-scored per query
+    int R;                     // bin = 4R rows
+    int metric;                // 0 cosine, 1 inner product
+    int64_t n_rows;
+    uint64_t* cand;            // [B][nb*4R]
+};
+hipError_t rq_rescore_launch(const RqRescoreArgs& a, int B, hipStream_t stream);
+
+// Pass 4: top-k of the candidates, certificate, outputs.
+struct RqFinalArgs {
+    const uint64_t* cand;      // [B][ncand]
+    int ncand;
+    const uint64_t* binkeys;   // [B][binkeys_stride]; entry nb is the best bin that was NOT re-scored
+    int binkeys_stride;
+    int nb;
+    int64_t nbins;             // bins of the shard
+    const double* qnorm64;
+    int metric;
+    float eps;                 // bound on |approximate - exact| in unit-query units
+    float max_row_norm;        // for the inner-product bound
+    int k;
+    int64_t row_offset;        // global id of the shard's row 0
+    int64_t n_rows;
+    float* out_scores;         // [B][k]
+    int64_t* out_rows;         // [B][k], -1 padded
+    uint64_t* out_keys;        // [B][k] optional (global-row keys for cross-shard merging), may be null
+    int* out_status;           // [B] 0 = certified exact, 1 = not certified
+};
+hipError_t rq_final_launch(const RqFinalArgs& a, int B, hipStream_t stream);
+
+// Merge G sorted key lists per query (cross-shard): in [B][G*k] -> top-k scores/rows/keys.
+hipError_t rq_merge_keys_launch(const uint64_t* keys, int n_per_query, int B, int k, float* out_scores, int64_t* out_rows,
+                                uint64_t* out_keys, hipStream_t stream);

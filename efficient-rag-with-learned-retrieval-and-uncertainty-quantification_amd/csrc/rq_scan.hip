@@ -1,0 +1,197 @@
+// rq_scan.hip -- pass 1 of the search: stream the fp16 corpus once from HBM, score it against a
+// block of <=64 queries on the matrix cores, and keep one maximum per (query, bin of 4*R rows).
+//
+// This is the arithmetic ChromaDB's cosine index performs behind
+// reference rag_uq/streaming_index.py:355-359 (collection.query), done exhaustively.
+//
+// Shape of the work (why it looks like this on MI355X):
+//   * HBM-bound: N*1536 B of corpus per query block, 64 FLOP/B -> the matrix cores run ~16% busy.
+//   * One workgroup = 4 waves; wave w keeps queries 16w..16w+15 in registers as the B operand of
+//     v_mfma_f32_16x16x32_f16 (24 fragments x 4 VGPRs), so LDS holds only corpus bytes.
+//   * Corpus rows reach LDS by LDS-DMA (global_load_lds_dwordx4): every wave-instruction moves
+//     1 KiB contiguous, no VGPRs, and stays in flight across barriers (counted vmcnt, raw s_barrier).
+//     A stage = 16 rows x 384 elements (12 KiB); S stages form a ring; S-1 are in flight.
+//   * The 768-byte stage rows alias in LDS banks, so the 16-byte chunks are XOR-swizzled with the
+//     row number on the DMA *source* address and on the ds_read_b128 address (LDS image stays
+//     lane-linear as LDS-DMA requires).
+//   * Accumulator layout of the 16x16 MFMA puts the query on the lane and 4 corpus rows in the 4
+//     result registers: the per-bin maximum is lane-local (no cross-lane traffic, no branches).
+//   * Output: pooled[query][bin] fp32 -- N/(4R)*64*4 B (1% of the corpus bytes at R=4).
+#include "rq_device.h"
+#include "rq_kernels.h"
+
+#define RQ_STAGE_BYTES 12288          // 16 rows x 768 B
+#define RQ_STAGE_CHUNKS 48            // 16-byte chunks per stage row
+#define RQ_NORM_BYTES 2048            // [2 parities][4 waves][64 floats]
+
+extern __shared__ __attribute__((aligned(16))) char rq_smem[];
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+template <int N>
+__device__ __forceinline__ void rq_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// S: ring depth; R: tiles per bin; NT: non-temporal corpus loads; PF: A fragments read from LDS ahead of
+// their MFMAs (1, 4, 6 or 12); OCC: waves per SIMD the register allocation must allow.
+template <int S, int R, bool NT, int PF, int OCC>
+__global__ __launch_bounds__(256, OCC) void rq_scan_kernel(RqScanArgs a) {
+    static_assert(S >= 3 && S <= 8, "ring depth");
+    static_assert(PF == 1 || PF == 4 || PF == 6 || PF == 12, "fragment prefetch group");
+    static_assert(R == 1 || R == 2 || R == 4, "tiles per bin");
+    constexpr int VM_KEEP = 3 * (S - 2);   // DMA ops of stages st+1 .. st+S-2 may stay in flight
+    constexpr unsigned AUX = NT ? 2u : 0u;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kg = lane >> 4;          // k-group of the MFMA operand / row group of the result
+    const int r16 = lane & 15;         // corpus row inside the tile (A operand), query inside the wave (D)
+
+    // ---- query fragments: B[k = 8*kg + j][col = r16] of k-step s  ==  qh[16*wave + r16][32*s + 8*kg + j]
+    rq_half8 qf[24];
+    {
+        const rq_half8* qsrc = (const rq_half8*)(a.qh + (size_t)(16 * wave + r16) * RQ_DPAD + 8 * kg);
+#pragma unroll
+        for (int s = 0; s < 24; ++s) qf[s] = qsrc[4 * s];
+#pragma unroll
+        for (int s = 0; s < 24; ++s) asm volatile("" : "+v"(qf[s]));   // loads retired before the DMA stream starts
+    }
+
+    // ---- per-lane DMA source offsets: LDS chunk p = 64*j + lane of a stage holds
+    //      row r = p / 48, source chunk c = (p % 48) ^ r   (r < 16, XOR stays inside a 16-chunk group)
+    unsigned voff[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int p = 64 * (wave * 3 + i) + lane;
+        const int r = p / RQ_STAGE_CHUNKS, cp = p % RQ_STAGE_CHUNKS;
+        voff[i] = (unsigned)(r * (RQ_DPAD * 2) + ((cp ^ r) << 4));
+    }
+    // ---- per-lane LDS read offsets: logical chunk 4*s + kg of row r16 sits at chunk ((4s+kg) ^ r16)
+    //      = 4*(s ^ (r16>>2)) + (kg ^ (r16&3));  split s = (s & ~3) | (s & 3): 4 lane bases + immediates
+    unsigned rbase[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        rbase[m] = (unsigned)(r16 * (RQ_STAGE_CHUNKS * 16) + ((kg ^ (r16 & 3)) << 4) + ((m ^ (r16 >> 2)) << 6));
+
+    const int G = gridDim.x, b = blockIdx.x;
+    const int nloc = (a.nquads > b) ? (a.nquads - b + G - 1) / G : 0;
+    const int nst = nloc * 8;
+    const char* xb = (const char*)a.x;
+    char* norm_lds = rq_smem + S * RQ_STAGE_BYTES;
+
+    auto issue = [&](int st, int slot) {
+        const int lq = st >> 3, t = (st >> 1) & 3, kh = st & 1;
+        const int64_t quad = (int64_t)b + (int64_t)lq * G;
+        const char* g = xb + (quad * RQ_QUAD_ROWS + t * RQ_TILE_ROWS) * (int64_t)(RQ_DPAD * 2) + kh * RQ_DPAD;
+        char* l = rq_smem + slot * RQ_STAGE_BYTES + (wave * 3) * 1024;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(g + voff[i]), (lds_ptr_t)(l + i * 1024), 16, 0, AUX);
+        if ((st & 7) == 0) {   // row scales of the quad, one private copy per wave (256 B)
+            const float* ns = a.row_scale + quad * RQ_QUAD_ROWS + lane;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)ns, (lds_ptr_t)(norm_lds + (((lq & 1) * 4 + wave) << 8)), 4, 0, 0);
+        }
+    };
+
+    int islot = 0;   // slot the next issued stage goes to
+    {
+        const int pre = nst < S - 1 ? nst : S - 1;
+        for (int st = 0; st < pre; ++st) { issue(st, islot); islot = (islot + 1 == S) ? 0 : islot + 1; }
+    }
+    int cslot = 0;   // slot of the stage being consumed
+    const float NEG_INF = -__builtin_huge_valf();
+
+    for (int lq = 0; lq < nloc; ++lq) {
+        const int64_t quad = (int64_t)b + (int64_t)lq * G;
+        float binmax[4 / R];
+#pragma unroll
+        for (int u = 0; u < 4 / R; ++u) binmax[u] = NEG_INF;
+        const char* nrow = norm_lds + (((lq & 1) * 4 + wave) << 8) + kg * 16;
+
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            rq_float4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                const int st = lq * 8 + t * 2 + kh;
+                if (st + S - 2 <= nst - 1) rq_wait_vmcnt<VM_KEEP>(); else rq_wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (st + S - 1 < nst) { issue(st + S - 1, islot); islot = (islot + 1 == S) ? 0 : islot + 1; }
+                const char* sb = rq_smem + cslot * RQ_STAGE_BYTES;
+                cslot = (cslot + 1 == S) ? 0 : cslot + 1;
+#pragma unroll
+                for (int g = 0; g < 12; g += PF) {
+                    rq_half8 av[PF];
+#pragma unroll
+                    for (int s = 0; s < PF; ++s) av[s] = *(const rq_half8*)(sb + rbase[(g + s) & 3] + (((g + s) & ~3) << 6));
+#pragma unroll
+                    for (int s = 0; s < PF; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[s], qf[kh * 12 + g + s], acc, 0, 0, 0);
+                }
+            }
+            // tile epilogue: D[row = 4*kg + i][query = r16]
+            const rq_float4 nv = *(const rq_float4*)(nrow + t * 64);
+            const int64_t row0 = quad * RQ_QUAD_ROWS + t * RQ_TILE_ROWS + 4 * kg;
+            float m = binmax[t / R];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float sc = acc[i] * nv[i];
+                sc = (row0 + i < a.n_rows) ? sc : NEG_INF;
+                m = fmaxf(m, sc);   // fmaxf drops NaN
+            }
+            binmax[t / R] = m;
+        }
+        if (16 * wave + r16 < a.nq_valid) {
+            float* dst = a.pooled + (int64_t)(16 * wave + r16) * a.pooled_stride + quad * (16 / R) + kg * (4 / R);
+            if constexpr (R == 4) {
+                dst[0] = binmax[0];
+            } else if constexpr (R == 2) {
+                *(float2*)dst = make_float2(binmax[0], binmax[1]);
+            } else {
+                *(float4*)dst = make_float4(binmax[0], binmax[1], binmax[2], binmax[3]);
+            }
+        }
+    }
+}
+
+template <int S, int R, bool NT, int PF, int OCC>
+static hipError_t rq_scan_launch_t(const RqScanArgs& a, int grid, hipStream_t stream) {
+    const size_t lds = (size_t)S * RQ_STAGE_BYTES + RQ_NORM_BYTES;
+    static unsigned long long attr_done = 0;   // one bit per device
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (!((attr_done >> (dev & 63)) & 1ull)) {
+        e = hipFuncSetAttribute((const void*)rq_scan_kernel<S, R, NT, PF, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done |= 1ull << (dev & 63);
+    }
+    hipLaunchKernelGGL((rq_scan_kernel<S, R, NT, PF, OCC>), dim3(grid), dim3(256), lds, stream, a);
+    return hipGetLastError();
+}
+
+template <int S, int PF, int OCC>
+static hipError_t rq_scan_launch_r(const RqScanArgs& a, int R, bool nt, int grid, hipStream_t stream) {
+    switch (R) {
+        case 4: return nt ? rq_scan_launch_t<S, 4, true, PF, OCC>(a, grid, stream) : rq_scan_launch_t<S, 4, false, PF, OCC>(a, grid, stream);
+        case 2: return nt ? rq_scan_launch_t<S, 2, true, PF, OCC>(a, grid, stream) : rq_scan_launch_t<S, 2, false, PF, OCC>(a, grid, stream);
+        case 1: return nt ? rq_scan_launch_t<S, 1, true, PF, OCC>(a, grid, stream) : rq_scan_launch_t<S, 1, false, PF, OCC>(a, grid, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+size_t rq_scan_lds_bytes(int S) { return (size_t)S * RQ_STAGE_BYTES + RQ_NORM_BYTES; }
+
+// variant = 10 * S + code:  code 0: PF 1, 3 waves/SIMD;  1: PF 4, 2 waves/SIMD;  2: PF 12, 2 waves/SIMD; 3: PF 6, 2 waves/SIMD
+hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int R, bool nt, int grid, hipStream_t stream) {
+    if (grid <= 0) return hipErrorInvalidValue;
+#define RQ_CASE(SS, PP, OO) if (S == SS && pf == PP) return rq_scan_launch_r<SS, PP, OO>(a, R, nt, grid, stream);
+    RQ_CASE(3, 1, 3) RQ_CASE(4, 1, 3)
+    RQ_CASE(4, 4, 2) RQ_CASE(5, 4, 2) RQ_CASE(6, 4, 2)
+    RQ_CASE(4, 6, 2) RQ_CASE(5, 6, 2) RQ_CASE(6, 6, 2)
+    RQ_CASE(4, 12, 2) RQ_CASE(5, 12, 2) RQ_CASE(6, 12, 2)
+#undef RQ_CASE
+    return hipErrorInvalidValue;
+}

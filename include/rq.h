@@ -1,0 +1,122 @@
+/* rq.h -- C ABI of the MI355X dense-retrieval backend (librq_hip.so).
+ *
+ * This is the drop-in boundary for the reference's dense path.  The reference has no native code;
+ * the calls below replace the two third-party services its DenseIndex talks to:
+ *
+ *   reference rag_uq/streaming_index.py          replaced by
+ *   ------------------------------------------   ---------------------------------------------
+ *   :252-263  chromadb client + collection       rq_index_create / rq_load
+ *   :306      collection.get()['ids'] (dedup)    host-side id table (Python), rq_index_size
+ *   :326-331  collection.add(embeddings=...)     rq_index_add_f32 / rq_index_add_f16
+ *   :355-359  collection.query(n_results=top_k)  rq_search (host buffers) / rq_search_device
+ *   :363-368  score = 1 - distance, best first   scores returned as cosine similarity, best first
+ *   :373      collection.count()                 rq_index_size
+ *   (Chroma persistence directory)               rq_save / rq_load
+ *
+ * Conventions: plain pointers and sizes, no torch types.  Host buffers are C-contiguous and owned by
+ * the caller; device memory is owned by the library.  Every int-returning call returns 0 on success
+ * or a negative RQ_E* code; the message is in rq_last_error() (thread local).  Calls block unless
+ * the name ends in _device.  One rq_index may be used from one thread at a time (the reference is
+ * single-threaded, streaming_index.py has no locks).  There is no CPU fallback: without a gfx950
+ * device every call that touches data fails with RQ_ENODEVICE.
+ *
+ * Score definition (pinned by oracle/dense_oracle.py, "parity unpinned" upstream -- Chroma's own
+ * arithmetic is not in the reference tree):
+ *   cosine:  s = fp32( dot64(q, x) / (||q||_64 * ||x||_64 + 1e-30) )   on the STORED fp16 row x
+ *   ip:      s = fp32( dot64(q, x) )
+ *   order:   s descending, then row ascending;  k_eff = min(k, N);  missing entries row = -1.
+ */
+#ifndef RQ_H
+#define RQ_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rq_index rq_index;
+
+enum { RQ_OK = 0, RQ_EINVAL = -1, RQ_ENODEVICE = -2, RQ_EHIP = -3, RQ_ENOMEM = -4, RQ_EIO = -5, RQ_EUNSUPPORTED = -6 };
+enum { RQ_METRIC_COSINE = 0, RQ_METRIC_IP = 1 };
+#define RQ_MAX_DIM 768
+#define RQ_MAX_K 1024
+
+/* Number of visible HIP devices (0 if none / no driver). */
+int rq_device_count(void);
+
+/* Create an empty index of `dim`-element rows (1 <= dim <= RQ_MAX_DIM) on device_ids[0].
+ * n_devices must be 1: one process per GPU; shards on other GPUs live in other processes and are
+ * merged with rq_merge_keys_device.  NULL on error. */
+rq_index* rq_index_create(int dim, int n_devices, const int* device_ids);
+void rq_index_destroy(rq_index* idx);
+
+int rq_index_dim(const rq_index* idx);
+int64_t rq_index_size(const rq_index* idx);
+/* Global id of this shard's row 0 (default 0); out_rows / keys carry row_offset + local row. */
+int rq_index_set_row_offset(rq_index* idx, int64_t row_offset);
+int rq_index_reserve(rq_index* idx, int64_t n_rows);
+
+/* Append n rows (row-major [n][dim]).  _f16: IEEE binary16 bit patterns, stored as given.
+ * _f32: rounded to fp16 (round-to-nearest-even); with normalize != 0 each row is first divided by
+ * its fp64 L2 norm (cosine is invariant to it and fp16 range is never exceeded).
+ * The fp64 norm of the STORED row is computed on device and kept for exact scoring. */
+int rq_index_add_f16(rq_index* idx, const uint16_t* rows, int64_t n_rows);
+int rq_index_add_f32(rq_index* idx, const float* rows, int64_t n_rows, int normalize);
+/* Same, rows already in device memory of the index's GPU. */
+int rq_index_add_f16_device(rq_index* idx, const void* d_rows, int64_t n_rows);
+int rq_index_add_f32_device(rq_index* idx, const float* d_rows, int64_t n_rows, int normalize);
+/* Copy stored rows [row_begin, row_begin+n) back to the host as fp16 bit patterns [n][dim]. */
+int rq_index_get_rows_f16(const rq_index* idx, int64_t row_begin, int64_t n_rows, uint16_t* out);
+
+/* Exact top-k of B queries ([B][dim] fp32, host).  out_scores [B][k], out_rows [B][k] (-1 padded).
+ * Results are exact (see score definition): an on-device certificate proves it per query, and the
+ * queries it cannot prove are re-run with a wider candidate set, finally with a full fp64 scan. */
+int rq_search(rq_index* idx, const float* queries, int B, int k, int metric, float* out_scores, int64_t* out_rows);
+
+/* Asynchronous form: all pointers are device pointers, work is enqueued on `stream` (a hipStream_t,
+ * NULL = default stream).  d_keys ([B][k] uint64, may be NULL) receives sortable (score, global row)
+ * keys for cross-shard merging.  d_status[B]: 0 = certified exact, 1 = not certified -- call
+ * rq_search_fixup_device after the stream has the results you need repaired.
+ * Calls on different streams may overlap; each stream has its own workspace. */
+int rq_search_device(rq_index* idx, const float* d_queries, int B, int k, int metric, float* d_scores, int64_t* d_rows,
+                     uint64_t* d_keys, int* d_status, void* stream);
+/* Synchronises `stream`, re-runs the queries whose d_status is non-zero with wider candidate sets /
+ * the exact scan, patches d_scores/d_rows/d_keys/d_status in place.  Returns the number repaired. */
+int rq_search_fixup_device(rq_index* idx, const float* d_queries, int B, int k, int metric, float* d_scores, int64_t* d_rows,
+                           uint64_t* d_keys, int* d_status, void* stream);
+
+/* Merge per-shard key lists: d_keys_in [B][n_per_query] (any order, 0 = empty) -> best k per query.
+ * d_rows receives the global row ids carried by the keys.  d_keys_out may be NULL. */
+int rq_merge_keys_device(const uint64_t* d_keys_in, int n_per_query, int B, int k, float* d_scores, int64_t* d_rows,
+                         uint64_t* d_keys_out, void* stream);
+
+/* Tuning / test hooks: "ring" (LDS stages 3..6), "bin_tiles" (1,2,4: bin = 4*bin_tiles rows),
+ * "wg_per_cu", "nt" (non-temporal corpus loads: 0, 1, -1 = auto), "slack_bins" (extra bins beyond k, -1 = auto),
+ * "eps" (certificate bound, <0 = derived default), "profile" (record HIP events around every scan launch). */
+int rq_set_option(rq_index* idx, const char* name, double value);
+double rq_get_option(const rq_index* idx, const char* name);
+
+typedef struct rq_timing {
+    double scan_ms;          /* sum of HIP-event durations of the scan kernel launches recorded */
+    int64_t scan_launches;   /* launches recorded (profile on) */
+    int64_t scan_bytes;      /* algorithmic corpus bytes of those launches: rows * 2 * dim_padded each */
+    int64_t searches;        /* rq_search* calls */
+    int64_t queries;         /* queries searched */
+    int64_t widened;         /* queries re-run with a wider candidate set */
+    int64_t exact_scans;     /* queries that needed the full fp64 scan */
+} rq_timing;
+int rq_get_timing(rq_index* idx, rq_timing* out);   /* synchronises the device */
+int rq_reset_timing(rq_index* idx);
+
+/* Flat-file persistence: <path>.meta (text), <path>.f16 (rows [N][dim] fp16). */
+int rq_save(const rq_index* idx, const char* path);
+rq_index* rq_load(const char* path, int n_devices, const int* device_ids);
+
+const char* rq_last_error(void);
+const char* rq_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RQ_H */
