@@ -54,6 +54,10 @@ struct Workspace {
     float* pooled = nullptr;
     uint64_t* binkeys = nullptr;
     uint64_t* cand = nullptr;
+    float* wgmax = nullptr;       // [bcap][RQ_WGMAX_STRIDE]
+    int* binlist = nullptr;       // [bcap][RQ_FAST_MAX_BINS]
+    int* bincount = nullptr;      // [bcap]
+    float* thr = nullptr;         // [bcap]
     // staging for rq_search_fixup_device
     int fix_bcap = 0, fix_k = 0;
     float* fix_q = nullptr;
@@ -74,7 +78,7 @@ struct rq_index {
     double* d_maxnorm = nullptr;   // device scalar, bits of the running max row norm
     double max_row_norm = 0.0;
     // options
-    int ring = 4, prefetch = 1, bin_tiles = 4, wg_per_cu = 3, nt = -1, slack_bins = -1, profile = 0;
+    int ring = 4, prefetch = 1, bin_tiles = 4, wg_per_cu = 3, nt = -1, slack_bins = -1, profile = 0, fast_tail = 1;
     double eps = -1.0;
     std::map<hipStream_t, Workspace> ws;
     hipStream_t own_stream = nullptr;
@@ -95,7 +99,7 @@ static const float RQ_EPS_DEFAULT = 7.0e-4f;
 
 static int nb_default(const rq_index* idx, int k) {
     const int per_quad = 16 / idx->bin_tiles;
-    int slack = idx->slack_bins >= 0 ? idx->slack_bins : std::max(8, k / 4);
+    int slack = idx->slack_bins >= 0 ? idx->slack_bins : std::max(8, k / 8);
     int nb = k + slack;
     nb = (nb + per_quad - 1) / per_quad * per_quad;
     return nb;
@@ -179,7 +183,7 @@ extern "C" rq_index* rq_index_create(int dim, int n_devices, const int* device_i
 }
 
 static void free_ws(Workspace& w) {
-    void* p[] = {w.qh, w.q32, w.qn, w.pooled, w.binkeys, w.cand, w.fix_q, w.fix_scores, w.fix_rows, w.fix_keys, w.fix_status};
+    void* p[] = {w.qh, w.q32, w.qn, w.pooled, w.binkeys, w.cand, w.wgmax, w.binlist, w.bincount, w.thr, w.fix_q, w.fix_scores, w.fix_rows, w.fix_keys, w.fix_status};
     for (void* q : p) if (q) hipFree(q);
     w = Workspace();
 }
@@ -293,6 +297,7 @@ extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     else if (s == "slack_bins") idx->slack_bins = (int)v;
     else if (s == "eps") idx->eps = v;
     else if (s == "profile") idx->profile = (int)v;
+    else if (s == "fast_tail") idx->fast_tail = (int)v;
     else return set_err(RQ_EINVAL, "unknown option '%s'", name);
     return RQ_OK;
 }
@@ -307,6 +312,7 @@ extern "C" double rq_get_option(const rq_index* idx, const char* name) {
     if (s == "slack_bins") return idx->slack_bins;
     if (s == "eps") return idx->eps < 0 ? RQ_EPS_DEFAULT : idx->eps;
     if (s == "profile") return idx->profile;
+    if (s == "fast_tail") return idx->fast_tail;
     if (s == "cu_count") return idx->cu_count;
     if (s == "max_row_norm") return idx->max_row_norm;
     return NAN;
@@ -330,6 +336,10 @@ static int ensure_ws(rq_index* idx, Workspace& w, int bpad, int64_t stride, int6
         if (int r = ensure(w.qh, 0, (size_t)bcap * RQ_DPAD)) return r;
         if (int r = ensure(w.q32, 0, (size_t)bcap * RQ_DPAD)) return r;
         if (int r = ensure(w.qn, 0, (size_t)bcap)) return r;
+        if (int r = ensure(w.wgmax, 0, (size_t)bcap * RQ_WGMAX_STRIDE)) return r;
+        if (int r = ensure(w.binlist, 0, (size_t)bcap * RQ_FAST_MAX_BINS)) return r;
+        if (int r = ensure(w.bincount, 0, (size_t)bcap)) return r;
+        if (int r = ensure(w.thr, 0, (size_t)bcap)) return r;
     }
     if (regrow_b || stride > w.pooled_stride) {
         const int64_t st = std::max(stride, w.pooled_stride);
@@ -381,16 +391,19 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     const int bpad = (B + 63) / 64 * 64;
     const int64_t stride = (nbins + 63) / 64 * 64;
     const int m = nb + 1;
-    const int64_t ncand = (int64_t)nb * binrows;
+    const bool fast = !exact && idx->fast_tail && m <= RQ_FAST_MAX_M && k <= RQ_FAST_MAX_K;
+    int rmax = 0;
+    if (fast) { rmax = std::min(RQ_FAST_MAX_BINS, std::max(32, 2 * m)); rmax = (rmax + 7) / 8 * 8; }
+    const int64_t ncand = fast ? (int64_t)rmax * binrows : (int64_t)nb * binrows;
     Workspace& w = idx->ws[s];
     if (int r = ensure_ws(idx, w, bpad, exact ? 64 : stride, exact ? 1 : m, ncand)) return r;
     const float* scale = idx->inv_norm;
     if (metric == RQ_METRIC_IP) { if (int r = ensure_ones(idx, s)) return r; scale = idx->ones; }
 
-    HIPCHK(rq_prep_queries_launch(d_q, idx->dim, B, bpad, w.qh, w.q32, w.qn, s));
+    HIPCHK(rq_prep_queries_launch(d_q, idx->dim, B, bpad, w.qh, w.q32, w.qn, w.bincount, s));
+    const int grid = (int)std::min<int64_t>(std::min<int64_t>(nquads, RQ_WGMAX_STRIDE), (int64_t)idx->cu_count * idx->wg_per_cu);
     if (!exact) {
         const bool nt = idx->nt < 0 ? (idx->n * (int64_t)(RQ_DPAD * 2) > ((int64_t)160 << 20)) : idx->nt != 0;
-        const int grid = (int)std::min<int64_t>(nquads, (int64_t)idx->cu_count * idx->wg_per_cu);
         for (int blk = 0; blk < bpad / 64; ++blk) {
             RqScanArgs a;
             a.x = idx->x;
@@ -401,6 +414,8 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             a.n_rows = idx->n;
             a.nquads = nquads;
             a.nq_valid = std::min(64, B - blk * 64);
+            a.wgmax = w.wgmax + (size_t)blk * 64 * RQ_WGMAX_STRIDE;
+            a.wgmax_stride = RQ_WGMAX_STRIDE;
             const bool prof = idx->profile && idx->ev_used < 16384;
             if (prof) {
                 if (idx->ev_used == idx->events.size()) {
@@ -413,6 +428,24 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             }
             HIPCHK(rq_scan_launch(a, idx->ring, idx->prefetch, R, nt, grid, s));
             if (prof) { HIPCHK(hipEventRecord(idx->events[idx->ev_used].second, s)); idx->ev_used++; }
+        }
+        if (fast) {
+            RqCollectArgs ca;
+            ca.pooled = w.pooled; ca.pooled_stride = w.pooled_stride; ca.nbins = nbins; ca.wgmax = w.wgmax;
+            ca.wgmax_stride = RQ_WGMAX_STRIDE; ca.nwg = grid; ca.m = m; ca.rmax = rmax; ca.binlist = w.binlist;
+            ca.bincount = w.bincount; ca.thr = w.thr;
+            HIPCHK(rq_collect_launch(ca, B, s));
+            RqRescoreListArgs rl;
+            rl.x = idx->x; rl.q32 = w.q32; rl.qnorm64 = w.qn; rl.rownorm64 = idx->rownorm64; rl.binlist = w.binlist;
+            rl.bincount = w.bincount; rl.rmax = rmax; rl.R = R; rl.metric = metric; rl.n_rows = idx->n; rl.cand = w.cand;
+            HIPCHK(rq_rescore_list_launch(rl, B, s));
+            RqFinalFastArgs ff;
+            ff.cand = w.cand; ff.bincount = w.bincount; ff.thr = w.thr; ff.rmax = rmax; ff.binrows = binrows; ff.qnorm64 = w.qn;
+            ff.metric = metric; ff.eps = idx->eps < 0 ? RQ_EPS_DEFAULT : (float)idx->eps;
+            ff.max_row_norm = (float)(idx->max_row_norm * (1.0 + 1e-6)); ff.k = k; ff.row_offset = idx->row_offset;
+            ff.n_rows = idx->n; ff.out_scores = d_scores; ff.out_rows = d_rows; ff.out_keys = d_keys; ff.out_status = d_status;
+            HIPCHK(rq_final_fast_launch(ff, B, s));
+            return RQ_OK;
         }
         HIPCHK(rq_select_bins_launch(w.pooled, w.pooled_stride, nbins, B, m, w.binkeys, s));
     }

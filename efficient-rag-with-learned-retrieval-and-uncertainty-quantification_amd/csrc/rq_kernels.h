@@ -12,7 +12,10 @@ struct RqScanArgs {
     int64_t n_rows;           // valid rows of the shard
     int nquads;               // ceil(n_rows / 64)
     int nq_valid;             // queries of this block that are real (<= 64)
+    float* wgmax;             // [64][wgmax_stride] best pooled value per (query, scan workgroup)
+    int wgmax_stride;         // >= grid
 };
+#define RQ_WGMAX_STRIDE 1024   // scan grids never exceed this many workgroups
 
 hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int R, bool nt, int grid, hipStream_t stream);
 size_t rq_scan_lds_bytes(int S);
@@ -26,7 +29,7 @@ hipError_t rq_pad_f16_launch(const void* src, int dim, int64_t n, void* dst_rows
 
 // Query preparation: qnorm64[q] = ||q|| (fp64); qh = fp16(q/||q||) padded to 768, slots >= B zero.
 hipError_t rq_prep_queries_launch(const float* q, int dim, int B, int Bpad, _Float16* qh, float* q32pad, double* qnorm64,
-                                  hipStream_t stream);
+                                  int* bincount, hipStream_t stream);
 
 // Pass 2: per query, the m best bins of pooled[q][0..nbins) as sorted keys (score desc, bin asc); 0-padded.
 hipError_t rq_select_bins_launch(const float* pooled, int64_t pooled_stride, int64_t nbins, int B, int m,
@@ -69,6 +72,33 @@ struct RqFinalArgs {
     int* out_status;           // [B] 0 = certified exact, 1 = not certified
 };
 hipError_t rq_final_launch(const RqFinalArgs& a, int B, hipStream_t stream);
+
+// ---- fast tail (m <= 128 bins, k <= 128): threshold from wgmax, unordered bin list, extraction top-k ----
+#define RQ_FAST_MAX_M 128
+#define RQ_FAST_MAX_K 128
+#define RQ_FAST_MAX_BINS 256   // bin-list capacity per query (rmax <= this)
+struct RqCollectArgs {
+    const float* pooled; int64_t pooled_stride; int64_t nbins;
+    const float* wgmax; int wgmax_stride; int nwg;   // nwg = scan grid size
+    int m;                     // threshold = m-th largest per-workgroup maximum (valid: >= m bins reach it)
+    int rmax;                  // bin-list capacity per query
+    int* binlist;              // [B][rmax]
+    int* bincount;             // [B], zeroed by the query-preparation kernel
+    float* thr;                // [B]
+};
+hipError_t rq_collect_launch(const RqCollectArgs& a, int B, hipStream_t stream);
+struct RqRescoreListArgs {
+    const void* x; const float* q32; const double* qnorm64; const double* rownorm64;
+    const int* binlist; const int* bincount; int rmax; int R; int metric; int64_t n_rows;
+    uint64_t* cand;            // [B][rmax*4R]
+};
+hipError_t rq_rescore_list_launch(const RqRescoreListArgs& a, int B, hipStream_t stream);
+struct RqFinalFastArgs {
+    const uint64_t* cand; const int* bincount; const float* thr; int rmax; int binrows;
+    const double* qnorm64; int metric; float eps; float max_row_norm; int k; int64_t row_offset; int64_t n_rows;
+    float* out_scores; int64_t* out_rows; uint64_t* out_keys; int* out_status;
+};
+hipError_t rq_final_fast_launch(const RqFinalFastArgs& a, int B, hipStream_t stream);
 
 // Merge G sorted key lists per query (cross-shard): in [B][G*k] -> top-k scores/rows/keys.
 hipError_t rq_merge_keys_launch(const uint64_t* keys, int n_per_query, int B, int k, float* out_scores, int64_t* out_rows,

@@ -102,6 +102,7 @@ __global__ __launch_bounds__(256, OCC) void rq_scan_kernel(RqScanArgs a) {
     }
     int cslot = 0;   // slot of the stage being consumed
     const float NEG_INF = -__builtin_huge_valf();
+    float wmax = NEG_INF;   // best pooled value this lane has produced (feeds the pass-2 threshold)
 
     for (int lq = 0; lq < nloc; ++lq) {
         const int64_t quad = (int64_t)b + (int64_t)lq * G;
@@ -143,6 +144,8 @@ __global__ __launch_bounds__(256, OCC) void rq_scan_kernel(RqScanArgs a) {
             }
             binmax[t / R] = m;
         }
+#pragma unroll
+        for (int u = 0; u < 4 / R; ++u) wmax = fmaxf(wmax, binmax[u]);
         if (16 * wave + r16 < a.nq_valid) {
             float* dst = a.pooled + (int64_t)(16 * wave + r16) * a.pooled_stride + quad * (16 / R) + kg * (4 / R);
             if constexpr (R == 4) {
@@ -154,6 +157,10 @@ __global__ __launch_bounds__(256, OCC) void rq_scan_kernel(RqScanArgs a) {
             }
         }
     }
+    // per-workgroup maximum of every query: wgmax[query][workgroup]
+    wmax = fmaxf(wmax, __shfl_xor(wmax, 16, 64));
+    wmax = fmaxf(wmax, __shfl_xor(wmax, 32, 64));
+    if (kg == 0 && 16 * wave + r16 < a.nq_valid) a.wgmax[(int64_t)(16 * wave + r16) * a.wgmax_stride + b] = wmax;
 }
 
 template <int S, int R, bool NT, int PF, int OCC>

@@ -126,7 +126,8 @@ hipError_t rq_pad_f16_launch(const void* src, int dim, int64_t n, void* dst, hip
 // --------------------------------------------------------------------------------------------
 // query preparation: one wave-sized pass per query (block = 256 threads, thread t owns 3 elements)
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rq_prep_queries_kernel(const float* q, int dim, int B, _Float16* qh, float* q32pad, double* qnorm64) {
+__global__ __launch_bounds__(256) void rq_prep_queries_kernel(const float* q, int dim, int B, _Float16* qh, float* q32pad, double* qnorm64,
+                                                              int* bincount) {
     __shared__ double part[4];
     const int qi = blockIdx.x, tid = threadIdx.x;
     float v[3];
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void rq_prep_queries_kernel(const float* q, in
     if ((tid & 63) == 0) part[tid >> 6] = acc;
     __syncthreads();
     const double nrm = sqrt((part[0] + part[1]) + (part[2] + part[3]));
-    if (tid == 0 && qi < B) qnorm64[qi] = nrm;
+    if (tid == 0 && qi < B) { qnorm64[qi] = nrm; bincount[qi] = 0; }
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
         const int i = p * 256 + tid;
@@ -151,8 +152,8 @@ __global__ __launch_bounds__(256) void rq_prep_queries_kernel(const float* q, in
     }
 }
 hipError_t rq_prep_queries_launch(const float* q, int dim, int B, int Bpad, _Float16* qh, float* q32pad, double* qnorm64,
-                                  hipStream_t stream) {
-    hipLaunchKernelGGL(rq_prep_queries_kernel, dim3(Bpad), dim3(256), 0, stream, q, dim, B, qh, q32pad, qnorm64);
+                                  int* bincount, hipStream_t stream) {
+    hipLaunchKernelGGL(rq_prep_queries_kernel, dim3(Bpad), dim3(256), 0, stream, q, dim, B, qh, q32pad, qnorm64, bincount);
     return hipGetLastError();
 }
 
@@ -362,5 +363,195 @@ hipError_t rq_merge_keys_launch(const uint64_t* keys, int n_per_query, int B, in
     if (k < 1 || k > RQ_SEL_L - RQ_SEL_THREADS || n_per_query < 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(rq_merge_keys_kernel, dim3(B), dim3(RQ_SEL_THREADS), 0, stream, keys, n_per_query, k, out_scores, out_rows,
                        out_keys);
+    return hipGetLastError();
+}
+
+// =============================================================================================
+// Fast tail (the common case: <= 128 bins wanted, k <= 128).  No sorting of bins at all:
+//   threshold T = m-th largest per-workgroup maximum written by the scan kernel.  At least m bins
+//   reach T (one per workgroup counted), so every bin with pooled >= T is a candidate and every
+//   other bin is bounded by T -- which is all the certificate needs.
+// =============================================================================================
+__global__ __launch_bounds__(256) void rq_collect_kernel(RqCollectArgs a) {
+    __shared__ float vals[256];
+    __shared__ float thr_s;
+    const int q = blockIdx.y, tid = threadIdx.x;
+    const float NEG_INF = -__builtin_huge_valf();
+    float v = NEG_INF;
+    const float* w = a.wgmax + (int64_t)q * a.wgmax_stride;
+    for (int i = tid; i < a.nwg; i += 256) v = fmaxf(v, w[i]);
+    vals[tid] = v;
+    if (tid == 0) thr_s = NEG_INF;
+    __syncthreads();
+    if (a.m <= 256) {
+        int rank = 0;
+        for (int j = 0; j < 256; ++j) { const float o = vals[j]; rank += ((o > v) || (o == v && j < tid)) ? 1 : 0; }
+        if (rank == a.m - 1) thr_s = v;   // exactly one thread has this rank
+    }
+    __syncthreads();
+    const float T = thr_s;
+    if (blockIdx.x == 0 && tid == 0) a.thr[q] = T;
+    const int64_t per = (a.nbins + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per;
+    const int64_t hi = lo + per < a.nbins ? lo + per : a.nbins;
+    const float* p = a.pooled + (int64_t)q * a.pooled_stride;
+    for (int64_t i = lo + tid; i < hi; i += 256) {
+        const float x = p[i];
+        if (x >= T) {
+            const int pos = atomicAdd(&a.bincount[q], 1);
+            if (pos < a.rmax) a.binlist[(int64_t)q * a.rmax + pos] = (int)i;
+        }
+    }
+}
+hipError_t rq_collect_launch(const RqCollectArgs& a, int B, hipStream_t stream) {
+    if (a.m < 1 || a.rmax < 1 || a.rmax > RQ_FAST_MAX_BINS) return hipErrorInvalidValue;
+    int chunks = (int)((a.nbins + 8191) / 8192);
+    chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);
+    hipLaunchKernelGGL(rq_collect_kernel, dim3(chunks, B), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+// grid (rmax, B); 4 waves, wave w re-scores rows w*R .. w*R+R-1 of its bin, all loads issued up front.
+template <int R>
+__global__ __launch_bounds__(256) void rq_rescore_list_kernel(RqRescoreListArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = blockIdx.y, slot = blockIdx.x;
+    int cnt = a.bincount[q];
+    cnt = cnt < a.rmax ? cnt : a.rmax;
+    if (slot >= cnt) return;
+    const int64_t bin = a.binlist[(int64_t)q * a.rmax + slot];
+    constexpr int binrows = 4 * R;
+    uint64_t* out = a.cand + ((int64_t)q * a.rmax + slot) * binrows;
+    const char* xb = (const char*)a.x;
+    rq_half4 xv[R][3];
+    int64_t rows[R];
+#pragma unroll
+    for (int jj = 0; jj < R; ++jj) {
+        rows[jj] = rq_bin_row(bin, R, wave * R + jj);
+        const int64_t rr = rows[jj] < a.n_rows ? rows[jj] : 0;
+        const char* r = xb + rr * (RQ_DPAD * 2);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) xv[jj][p] = *(const rq_half4*)(r + p * 512 + lane * 8);
+    }
+    float qv[12];
+    const float* qp = a.q32 + (size_t)q * RQ_DPAD;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const float4 t = *(const float4*)(qp + p * 256 + 4 * lane);
+        qv[p * 4 + 0] = t.x; qv[p * 4 + 1] = t.y; qv[p * 4 + 2] = t.z; qv[p * 4 + 3] = t.w;
+    }
+    const double qn = a.qnorm64[q];
+#pragma unroll
+    for (int jj = 0; jj < R; ++jj) {
+        double dot = 0.0;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dot += (double)qv[p * 4 + e] * (double)(float)xv[jj][p][e];
+        dot = rq_wave_sum(dot);
+        if (lane == 0) {
+            uint64_t key = 0;
+            if (rows[jj] < a.n_rows) {
+                double s = dot;
+                if (a.metric == 0) s = dot / (qn * a.rownorm64[rows[jj]] + 1e-30);
+                key = rq_make_key(rq_sanitize((float)s), (uint32_t)rows[jj]);
+            }
+            out[wave * R + jj] = key;
+        }
+    }
+}
+hipError_t rq_rescore_list_launch(const RqRescoreListArgs& a, int B, hipStream_t stream) {
+    if (a.rmax < 1 || B < 1) return hipErrorInvalidValue;
+    const dim3 grid(a.rmax, B);
+    switch (a.R) {
+        case 4: hipLaunchKernelGGL(rq_rescore_list_kernel<4>, grid, dim3(256), 0, stream, a); break;
+        case 2: hipLaunchKernelGGL(rq_rescore_list_kernel<2>, grid, dim3(256), 0, stream, a); break;
+        case 1: hipLaunchKernelGGL(rq_rescore_list_kernel<1>, grid, dim3(256), 0, stream, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ uint64_t rq_wave_max_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// One 256-thread workgroup per query: <= 4096 candidate keys in registers, k rounds of "extract the maximum".
+__global__ __launch_bounds__(256) void rq_final_fast_kernel(RqFinalFastArgs a) {
+    __shared__ uint64_t wbest[2][4];
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t kk = a.k < a.n_rows ? a.k : a.n_rows;
+    const double qn = a.qnorm64[q];
+    float* os = a.out_scores + (int64_t)q * a.k;
+    int64_t* orow = a.out_rows + (int64_t)q * a.k;
+    uint64_t* ok = a.out_keys ? a.out_keys + (int64_t)q * a.k : nullptr;
+    if (qn == 0.0) {   // every score is exactly 0: rows 0 .. kk-1 (score desc, row asc)
+        for (int j = tid; j < a.k; j += 256) {
+            const bool v = j < kk;
+            os[j] = 0.f;
+            orow[j] = v ? a.row_offset + j : -1;
+            if (ok) ok[j] = v ? rq_make_key(0.f, (uint32_t)(a.row_offset + j)) : 0;
+        }
+        if (tid == 0) a.out_status[q] = 0;
+        return;
+    }
+    const int total = a.bincount[q];
+    const int cnt = total < a.rmax ? total : a.rmax;
+    const int n = cnt * a.binrows;
+    const uint64_t* c = a.cand + (int64_t)q * a.rmax * a.binrows;
+    uint64_t key[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int j = i * 256 + tid; key[i] = j < n ? c[j] : 0; }
+    uint64_t best = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) best = key[i] > best ? key[i] : best;
+    int have = 0;
+    uint64_t kth = 0;
+    for (int j = 0; j < a.k; ++j) {
+        const uint64_t wm = rq_wave_max_u64(best);
+        if (lane == 0) wbest[j & 1][wave] = wm;
+        __syncthreads();
+        uint64_t win = wbest[j & 1][0];
+#pragma unroll
+        for (int w2 = 1; w2 < 4; ++w2) win = wbest[j & 1][w2] > win ? wbest[j & 1][w2] : win;
+        if (win == 0) break;   // uniform: candidates exhausted
+        have = j + 1;
+        kth = win;
+        if (tid == 0) {
+            const float s = rq_key_score(win);
+            const int64_t grow = a.row_offset + (int64_t)rq_key_index(win);
+            os[j] = s;
+            orow[j] = grow;
+            if (ok) ok[j] = rq_make_key(s, (uint32_t)grow);
+        }
+        if (best == win) {   // keys are unique: exactly one thread owns the winner
+            best = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { if (key[i] == win) key[i] = 0; best = key[i] > best ? key[i] : best; }
+        }
+    }
+    for (int j = have + tid; j < a.k; j += 256) { os[j] = 0.f; orow[j] = -1; if (ok) ok[j] = 0; }
+    if (tid == 0) {
+        const float T = a.thr[q];
+        int good;
+        if (total > a.rmax) good = 0;                                   // bin list overflowed
+        else if (T == -__builtin_huge_valf()) good = have >= kk;        // every bin was a candidate
+        else if (have < kk) good = 0;
+        else {
+            const double bound = a.metric == 0 ? (double)T + (double)a.eps
+                                               : ((double)T + (double)a.eps * (double)a.max_row_norm) * qn * (1.0 + 1e-6);
+            good = (float)bound < rq_key_score(kth);
+        }
+        a.out_status[q] = good ? 0 : 1;
+    }
+}
+hipError_t rq_final_fast_launch(const RqFinalFastArgs& a, int B, hipStream_t stream) {
+    if (a.k < 1 || a.k > RQ_FAST_MAX_K || a.rmax * a.binrows > 4096) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rq_final_fast_kernel, dim3(B), dim3(256), 0, stream, a);
     return hipGetLastError();
 }

@@ -27,16 +27,17 @@ def check(idx, x16, q, k, metric=0, tag=""):
 
 allok = True
 log("devices:", nat.device_count(), nat.load_library().rq_version())
-for (n, dim) in [(1000, 768), (37, 32), (5000, 384), (100000, 768)]:
+for (n, dim, fast) in [(1000, 768, 1), (37, 32, 1), (5000, 384, 1), (100000, 768, 1), (100000, 768, 0), (1000, 768, 0)]:
     x16 = orc.synthetic_corpus(n, dim, seed=1234)
     idx = nat.NativeIndex(dim, 0)
+    idx.set_option("fast_tail", fast)
     idx.add_f16(x16[: n // 2]); idx.add_f16(x16[n // 2:])
     assert len(idx) == n
     back = idx.get_rows_f16(0, n)
     assert (back.view(np.uint16) == x16.view(np.uint16)).all(), "stored rows differ"
     for B, k in [(1, 10), (5, 1), (64, 10), (70, 50), (3, 100)]:
         q = orc.synthetic_queries(B, dim, seed=4321 + B)
-        allok &= check(idx, x16, q, k, 0, f"dim={dim}")
+        allok &= check(idx, x16, q, k, 0, f"dim={dim} fast={fast}")
     q = orc.synthetic_queries(8, dim, seed=99)
     allok &= check(idx, x16, q, 10, 1, f"dim={dim} ip")
     idx.close()
@@ -79,16 +80,24 @@ qs = [torch.randn((B, 768), device=dev, generator=g) for _ in range(8)]
 sc = torch.empty((B, k), device=dev); rows = torch.empty((B, k), device=dev, dtype=torch.int64)
 keys = torch.empty((B, k), device=dev, dtype=torch.int64); st = torch.empty((B,), device=dev, dtype=torch.int32)
 res = []
-def run(tag, iters=30):
+streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+outs = [(torch.empty((B, 128), device=dev), torch.empty((B, 128), device=dev, dtype=torch.int64),
+         torch.empty((B, 128), device=dev, dtype=torch.int64), torch.empty((B,), device=dev, dtype=torch.int32)) for _ in range(2)]
+def run(tag, iters=40, nstreams=1, k=10):
     idx.set_option("profile", 1); idx.reset_timing()
-    for i in range(5):
-        idx.search_device(qs[i % 8], B, k, 0, sc, rows, keys, st, 0)
+    def go(i):
+        j = i % nstreams
+        o = outs[j]
+        idx.search_device(qs[i % 8], B, k, 0, o[0], o[1], o[2], o[3], streams[j].cuda_stream)
+    for i in range(6):
+        go(i)
     torch.cuda.synchronize(); idx.reset_timing()
     t0 = time.perf_counter()
     for i in range(iters):
-        idx.search_device(qs[i % 8], B, k, 0, sc, rows, keys, st, 0)
+        go(i)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
+    st = outs[0][3]
     t = idx.timing()
     scan_us = t["scan_ms"] / max(t["scan_launches"], 1) * 1e3
     gbs = N * 1536 / (scan_us * 1e-6) / 1e9
@@ -96,19 +105,21 @@ def run(tag, iters=30):
     log(f"[perf] {tag}: scan {scan_us:8.1f} us  {gbs:7.1f} GB/s ({gbs/8000:.1%} of 8 TB/s)   end-to-end {dt*1e6:8.1f} us/batch  {B/dt:9.0f} q/s  uncertified={bad}")
     res.append(dict(tag=tag, scan_us=scan_us, gbs=gbs, e2e_us=dt * 1e6, qps=B / dt, uncertified=bad))
 
-for ring, pf, wg in [(4, 1, 3), (3, 1, 3), (4, 4, 2), (6, 4, 2), (6, 12, 2), (5, 6, 2), (6, 6, 2), (4, 12, 2), (4, 1, 2), (4, 1, 4)]:
-    for nt in (1, 0):
-        idx.set_option("ring", ring); idx.set_option("prefetch", pf); idx.set_option("wg_per_cu", wg); idx.set_option("nt", nt)
-        try:
-            run(f"ring={ring} pf={pf} wg/cu={wg} nt={nt}")
-        except Exception as e:
-            log("variant failed", ring, pf, wg, nt, e)
+for ring, pf, wg in [(4, 1, 3), (4, 4, 2), (6, 12, 2)]:
+    idx.set_option("ring", ring); idx.set_option("prefetch", pf); idx.set_option("wg_per_cu", wg); idx.set_option("nt", 1)
+    for ns in (1, 2):
+        run(f"ring={ring} pf={pf} wg/cu={wg} streams={ns} k=10", nstreams=ns)
+idx.set_option("ring", 4); idx.set_option("prefetch", 1); idx.set_option("wg_per_cu", 3)
+for kk in (1, 50, 100):
+    run(f"default streams=2 k={kk}", nstreams=2, k=kk)
+idx.set_option("fast_tail", 0); run("generic tail streams=2 k=10", nstreams=2); idx.set_option("fast_tail", 1)
 out["perf"] = res
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "probe.json"), "w"), indent=1)
 # spot-check the 1M result against the oracle on a 2-query slice (oracle over 1M rows in chunks)
-q_host = qs[0][:2].cpu().numpy()
-s_host, r_host = idx.search(q_host, 10, 0)
+q_host = qs[0][:3].cpu().numpy()
 xs = idx.get_rows_f16(0, N)
-gs, gr = orc.dense_topk(q_host, xs, 10, 0)
-log("[1M parity] rows_equal=", bool((r_host == gr).all()), "max|ds|=", float(np.abs(s_host - gs).max()))
+for kk in (10, 100):
+    s_host, r_host = idx.search(q_host, kk, 0)
+    gs, gr = orc.dense_topk(q_host, xs, kk, 0)
+    log(f"[1M parity k={kk}] rows_equal=", bool((r_host == gr).all()), "max|ds|=", float(np.abs(s_host - gs).max()), idx.timing())
