@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""bench.py -- queries/sec of the dense-retrieval hot path on MI355X (BASELINE.json metric).
+
+Workload (BASELINE.json configs[1]): 1M x 768 fp16 synthetic corpus, batches of 64 queries, top-10,
+exact results.  A "step" = one 64-query batch searched against the whole corpus.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+N > 1: the corpus is row-sharded (rank r holds rows [r*N/G, (r+1)*N/G)), every rank searches every
+batch on its shard, the per-shard (score, row) keys are exchanged with one RCCL all-gather per
+GATHER_EVERY batches and merged on the GPU.  Total work is fixed as N grows => "scaling": "strong".
+
+Rank 0 prints ONE JSON line.  Extra objects: "roofline" (scan kernel: algorithmic bytes / HIP-event
+duration measured here, over the timed region) and, at N = 1, "cpu_baseline" (oracle port, fp32
+OpenBLAS brute force on this box's host cores, bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_ROWS = 1_000_000
+DIM = 768
+BATCH = 64
+TOPK = 10
+N_QUERY_BATCHES = 16          # distinct query batches cycled through the steps
+GATHER_EVERY = 8              # batches per all-gather (N > 1)
+CHUNK_ROWS = 125_000          # corpus generated in chunks seeded by global chunk id: same corpus for any N
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--rows", type=int, default=N_ROWS)
+    ap.add_argument("--k", type=int, default=TOPK)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=2)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import rag_uq_amd  # noqa: F401
+    from rag_uq_amd import _native as nat
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    # RQ_BENCH_FORCE_COMM=1 exercises the all-gather + merge path on a single rank (rehearsal on a 1-GPU box)
+    use_comm = world > 1 or os.environ.get("RQ_BENCH_FORCE_COMM") == "1"
+    if use_comm:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n_total, k, B = args.rows, args.k, BATCH
+    n_chunks = (n_total + CHUNK_ROWS - 1) // CHUNK_ROWS
+    c_lo, c_hi = rank * n_chunks // world, (rank + 1) * n_chunks // world
+    row_lo = min(c_lo * CHUNK_ROWS, n_total)
+    row_hi = min(c_hi * CHUNK_ROWS, n_total)
+    n_local = row_hi - row_lo
+
+    # ---- corpus shard: synthetic Gaussian rows, unit norm, fp16, generated in HBM ---------------
+    idx = nat.NativeIndex(DIM, local_rank)
+    idx.reserve(max(n_local, 1))
+    idx.set_row_offset(row_lo)
+    for c in range(c_lo, c_hi):
+        g = torch.Generator(device=dev)
+        g.manual_seed(1235 + c)
+        n = min(CHUNK_ROWS, n_total - c * CHUNK_ROWS)
+        x = torch.randn((n, DIM), device=dev, generator=g, dtype=torch.float32)
+        x = torch.nn.functional.normalize(x, dim=1).half().contiguous()
+        idx.add_f16_device(x, n)
+        del x
+    gq = torch.Generator(device=dev)
+    gq.manual_seed(4321)
+    queries = [torch.randn((B, DIM), device=dev, generator=gq, dtype=torch.float32) for _ in range(N_QUERY_BATCHES)]
+    torch.cuda.synchronize()
+
+    # ---- per-batch output slots (results stay in HBM) -----------------------------------------------
+    def slot():
+        return dict(scores=torch.empty((B, k), device=dev), rows=torch.empty((B, k), device=dev, dtype=torch.int64),
+                    keys=torch.empty((B, k), device=dev, dtype=torch.int64), status=torch.zeros((B,), device=dev, dtype=torch.int32))
+    slots = [slot() for _ in range(N_QUERY_BATCHES)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
+    comm_stream = torch.cuda.Stream(device=dev)
+    if use_comm:
+        ring = [torch.zeros((GATHER_EVERY, B, k), device=dev, dtype=torch.int64) for _ in range(2)]
+        gathered = [torch.zeros((world, GATHER_EVERY, B, k), device=dev, dtype=torch.int64) for _ in range(2)]
+        m_scores = torch.empty((GATHER_EVERY * B, k), device=dev)
+        m_rows = torch.empty((GATHER_EVERY * B, k), device=dev, dtype=torch.int64)
+    pending = {"n": 0, "ring": 0, "ev": [None, None]}
+
+    def flush():
+        """all-gather the local keys of the pending batches (one RCCL call) and merge them on the GPU"""
+        if not use_comm or pending["n"] == 0:
+            return
+        r = pending["ring"]
+        for s in streams:
+            comm_stream.wait_stream(s)
+        with torch.cuda.stream(comm_stream):
+            dist.all_gather_into_tensor(gathered[r], ring[r])
+            merged_in = gathered[r].permute(1, 2, 0, 3).contiguous()   # [G][B][world][k]
+            nat.merge_keys_device(merged_in, world * k, GATHER_EVERY * B, k, m_scores, m_rows, None, comm_stream.cuda_stream)
+            pending["ev"][r] = comm_stream.record_event()
+        pending["n"] = 0
+        pending["ring"] = 1 - r
+        # the ring refilled next was read by the gather issued GATHER_EVERY batches ago: wait for that one only
+        ev = pending["ev"][1 - r]
+        if ev is not None:
+            for s in streams:
+                s.wait_event(ev)
+
+    def step(i: int) -> None:
+        j = i % N_QUERY_BATCHES
+        s = streams[i % len(streams)]
+        o = slots[j]
+        keys = ring[pending["ring"]][pending["n"]] if use_comm else o["keys"]
+        idx.search_device(queries[j], B, k, nat.METRIC_COSINE, o["scores"], o["rows"], keys, o["status"], s.cuda_stream)
+        if use_comm:
+            pending["n"] += 1
+            if pending["n"] == GATHER_EVERY:
+                flush()
+
+    def fixup_all() -> int:
+        """certificate check of every slot (inside the timed region): repairs uncertified queries exactly"""
+        fixed = 0
+        nslots = min(N_QUERY_BATCHES, args.steps)
+        for j in range(nslots):
+            o = slots[j]
+            fixed += idx.search_fixup_device(queries[j], B, k, nat.METRIC_COSINE, o["scores"], o["rows"], o["keys"], o["status"], 0)
+        if use_comm:
+            t = torch.tensor([fixed], device=dev, dtype=torch.int64)
+            dist.all_reduce(t)
+            if int(t.item()) > 0:
+                # rare: some shard repaired a query after its keys were gathered -> redo those batches synchronously
+                one = torch.zeros((world, B, k), device=dev, dtype=torch.int64)
+                for j in range(nslots):
+                    o = slots[j]
+                    idx.search_device(queries[j], B, k, nat.METRIC_COSINE, o["scores"], o["rows"], o["keys"], o["status"], 0)
+                    idx.search_fixup_device(queries[j], B, k, nat.METRIC_COSINE, o["scores"], o["rows"], o["keys"], o["status"], 0)
+                    dist.all_gather_into_tensor(one, o["keys"])
+                    nat.merge_keys_device(one.permute(1, 0, 2).contiguous(), world * k, B, k, o["scores"], o["rows"], None, 0)
+        return fixed
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if use_comm:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    flush()
+    sync_all()
+    idx.set_option("profile", 1)
+    idx.reset_timing()
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    flush()
+    torch.cuda.synchronize()
+    fixed = fixup_all()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if use_comm:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    timing = idx.timing()
+    idx.set_option("profile", 0)
+
+    qps = args.steps * B / elapsed
+    scan_us = timing["scan_ms"] * 1e3 / max(timing["scan_launches"], 1)
+    algo_bytes = n_local * DIM * 2            # one pass over the fp16 shard per launch
+    achieved = algo_bytes / (scan_us * 1e-6) / 1e9 if scan_us > 0 else 0.0
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_scan.json")
+    if world == 1 and n_total == N_ROWS and os.path.exists(pmc_path):
+        try:
+            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "queries/sec @ Recall@10=1.0 (exact top-10), 1M x 768 fp16 corpus, batch-64 queries",
+        "value": qps,
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f16",
+        "data": "synthetic",
+        "config": {"workload": f"{n_total}x{DIM} fp16 corpus, batch-{B} queries, top-{k}, cosine, exact (certified) results",
+                   "rows_per_gpu": n_local, "streams": len(streams), "gather_every": GATHER_EVERY if use_comm else 0,
+                   "parallelism": f"row-shard x{world}"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "rq_scan_kernel",
+                     "avg_launch_us": scan_us, "launches": timing["scan_launches"], "algorithmic_bytes_per_launch": algo_bytes},
+        "repaired_queries": fixed,
+        "exact_scans": timing["exact_scans"],
+    }
+
+    # ---- outside the timed region: recall vs the oracle, CPU baseline (rank 0, N = 1 only) ----------
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import dense_oracle as orc
+        x16 = idx.get_rows_f16(0, n_local)
+        q_host = queries[0].cpu().numpy()
+        nchk = 4
+        gs, gr = orc.dense_topk(q_host[:nchk], x16, k)
+        got_r = slots[0]["rows"][:nchk].cpu().numpy()
+        got_s = slots[0]["scores"][:nchk].cpu().numpy()
+        out["recall_at_10"] = orc.recall_at_k(got_r, gr)
+        out["ids_exact"] = bool((got_r == gr).all())
+        out["max_abs_score_err"] = float(np.abs(got_s - gs).max())
+        cores = len(os.sched_getaffinity(0))
+        cpu = orc.Fp32BruteForce(x16)
+        del x16
+        cpu.search(q_host, k)   # warm up BLAS threads
+        nb, tcpu = 0, 0.0
+        while tcpu < 12.0 and nb < 64:
+            qh = queries[(nb + 1) % N_QUERY_BATCHES].cpu().numpy()
+            tb = time.perf_counter()
+            cpu.search(qh, k)
+            tcpu += time.perf_counter() - tb
+            nb += 1
+        out["cpu_baseline"] = {"value": nb * B / tcpu, "unit": "queries/s", "cores": cores, "kind": "port",
+                               "sample": f"{nb} batches of {B} queries over the full {n_local}x{DIM} corpus "
+                                         f"(oracle/dense_oracle.py Fp32BruteForce: fp32 OpenBLAS GEMM + argpartition)"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    idx.close()
+    if use_comm:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

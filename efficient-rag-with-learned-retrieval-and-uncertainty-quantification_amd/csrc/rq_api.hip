@@ -239,6 +239,10 @@ static int add_device_common(rq_index* idx, const void* d_rows, int64_t n_rows, 
     if (!idx || (!d_rows && n_rows > 0) || n_rows < 0) return set_err(RQ_EINVAL, "bad add arguments");
     if (n_rows == 0) return RQ_OK;
     if (int r = use_device(idx)) return r;
+    // The rows may have been produced on any stream of the caller (e.g. torch's): wait for all of it.
+    // Appending is not a hot path; searches in flight on other streams are drained too, which also
+    // makes it safe to reallocate the shard below.
+    HIPCHK(hipDeviceSynchronize());
     if (int r = grow(idx, idx->n + n_rows)) return r;
     char* dst = idx->x + (size_t)idx->n * RQ_DPAD * 2;
     if (is_f32) HIPCHK(rq_convert_f32_launch((const float*)d_rows, idx->dim, n_rows, normalize, dst, idx->own_stream));

@@ -373,7 +373,7 @@ hipError_t rq_merge_keys_launch(const uint64_t* keys, int n_per_query, int B, in
 //   other bin is bounded by T -- which is all the certificate needs.
 // =============================================================================================
 __global__ __launch_bounds__(256) void rq_collect_kernel(RqCollectArgs a) {
-    __shared__ float vals[256];
+    __shared__ __attribute__((aligned(16))) float vals[256];
     __shared__ float thr_s;
     const int q = blockIdx.y, tid = threadIdx.x;
     const float NEG_INF = -__builtin_huge_valf();
@@ -385,29 +385,46 @@ __global__ __launch_bounds__(256) void rq_collect_kernel(RqCollectArgs a) {
     __syncthreads();
     if (a.m <= 256) {
         int rank = 0;
-        for (int j = 0; j < 256; ++j) { const float o = vals[j]; rank += ((o > v) || (o == v && j < tid)) ? 1 : 0; }
+#pragma unroll 4
+        for (int j = 0; j < 256; j += 4) {
+            const float4 o = *(const float4*)&vals[j];   // broadcast read
+            rank += ((o.x > v) || (o.x == v && j + 0 < tid)) ? 1 : 0;
+            rank += ((o.y > v) || (o.y == v && j + 1 < tid)) ? 1 : 0;
+            rank += ((o.z > v) || (o.z == v && j + 2 < tid)) ? 1 : 0;
+            rank += ((o.w > v) || (o.w == v && j + 3 < tid)) ? 1 : 0;
+        }
         if (rank == a.m - 1) thr_s = v;   // exactly one thread has this rank
     }
     __syncthreads();
     const float T = thr_s;
     if (blockIdx.x == 0 && tid == 0) a.thr[q] = T;
-    const int64_t per = (a.nbins + gridDim.x - 1) / gridDim.x;
-    const int64_t lo = (int64_t)blockIdx.x * per;
-    const int64_t hi = lo + per < a.nbins ? lo + per : a.nbins;
+    // this workgroup's 4096 bins: 4 x float4 per thread, all loads issued before the first compare
     const float* p = a.pooled + (int64_t)q * a.pooled_stride;
-    for (int64_t i = lo + tid; i < hi; i += 256) {
-        const float x = p[i];
-        if (x >= T) {
-            const int pos = atomicAdd(&a.bincount[q], 1);
-            if (pos < a.rmax) a.binlist[(int64_t)q * a.rmax + pos] = (int)i;
+    const int64_t base = (int64_t)blockIdx.x * 4096;
+    float4 v4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t i = base + (int64_t)u * 1024 + tid * 4;   // pooled_stride is a multiple of 64: in-bounds up to the stride
+        v4[u] = (i < a.pooled_stride) ? *(const float4*)(p + i) : make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const float xs[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t i = base + (int64_t)u * 1024 + tid * 4 + e;
+            if (i < a.nbins && xs[e] >= T) {
+                const int pos = atomicAdd(&a.bincount[q], 1);
+                if (pos < a.rmax) a.binlist[(int64_t)q * a.rmax + pos] = (int)i;
+            }
         }
     }
 }
 hipError_t rq_collect_launch(const RqCollectArgs& a, int B, hipStream_t stream) {
     if (a.m < 1 || a.rmax < 1 || a.rmax > RQ_FAST_MAX_BINS) return hipErrorInvalidValue;
-    int chunks = (int)((a.nbins + 8191) / 8192);
-    chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);
-    hipLaunchKernelGGL(rq_collect_kernel, dim3(chunks, B), dim3(256), 0, stream, a);
+    const int64_t chunks = (a.nbins + 4095) / 4096;
+    if (chunks < 1 || chunks > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rq_collect_kernel, dim3((unsigned)chunks, B), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -425,10 +442,12 @@ __global__ __launch_bounds__(256) void rq_rescore_list_kernel(RqRescoreListArgs 
     const char* xb = (const char*)a.x;
     rq_half4 xv[R][3];
     int64_t rows[R];
+    double rn[R];
 #pragma unroll
     for (int jj = 0; jj < R; ++jj) {
         rows[jj] = rq_bin_row(bin, R, wave * R + jj);
         const int64_t rr = rows[jj] < a.n_rows ? rows[jj] : 0;
+        rn[jj] = a.rownorm64[rr];
         const char* r = xb + rr * (RQ_DPAD * 2);
 #pragma unroll
         for (int p = 0; p < 3; ++p) xv[jj][p] = *(const rq_half4*)(r + p * 512 + lane * 8);
@@ -453,7 +472,7 @@ __global__ __launch_bounds__(256) void rq_rescore_list_kernel(RqRescoreListArgs 
             uint64_t key = 0;
             if (rows[jj] < a.n_rows) {
                 double s = dot;
-                if (a.metric == 0) s = dot / (qn * a.rownorm64[rows[jj]] + 1e-30);
+                if (a.metric == 0) s = dot / (qn * rn[jj] + 1e-30);
                 key = rq_make_key(rq_sanitize((float)s), (uint32_t)rows[jj]);
             }
             out[wave * R + jj] = key;
@@ -484,9 +503,13 @@ __device__ __forceinline__ uint64_t rq_wave_max_u64(uint64_t v) {
 // One 256-thread workgroup per query: <= 4096 candidate keys in registers, k rounds of "extract the maximum".
 __global__ __launch_bounds__(256) void rq_final_fast_kernel(RqFinalFastArgs a) {
     __shared__ uint64_t wbest[2][4];
+    __shared__ uint64_t skeys[1024];
+    __shared__ uint64_t skth;
+    __shared__ int snz;
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t kk = a.k < a.n_rows ? a.k : a.n_rows;
     const double qn = a.qnorm64[q];
+    const float T = a.thr[q];
     float* os = a.out_scores + (int64_t)q * a.k;
     int64_t* orow = a.out_rows + (int64_t)q * a.k;
     uint64_t* ok = a.out_keys ? a.out_keys + (int64_t)q * a.k : nullptr;
@@ -512,6 +535,47 @@ __global__ __launch_bounds__(256) void rq_final_fast_kernel(RqFinalFastArgs a) {
     for (int i = 0; i < 16; ++i) best = key[i] > best ? key[i] : best;
     int have = 0;
     uint64_t kth = 0;
+    if (n <= 1024) {
+        // small candidate set: rank every key against all others (LDS broadcast reads), write by rank
+        if (tid == 0) { skth = 0; snz = 0; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) skeys[i * 256 + tid] = key[i];
+        __syncthreads();
+        int rank[4] = {0, 0, 0, 0};
+        // keys are laid out i*256 + tid: only the first ceil(n/256) registers of a thread can be non-empty
+        if (n <= 256) {
+#pragma unroll 4
+            for (int j = 0; j < n; ++j) rank[0] += skeys[j] > key[0] ? 1 : 0;
+        } else if (n <= 512) {
+#pragma unroll 4
+            for (int j = 0; j < n; ++j) { const uint64_t o = skeys[j]; rank[0] += o > key[0] ? 1 : 0; rank[1] += o > key[1] ? 1 : 0; }
+        } else {
+#pragma unroll 2
+            for (int j = 0; j < n; ++j) {
+                const uint64_t o = skeys[j];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rank[i] += o > key[i] ? 1 : 0;
+            }
+        }
+        int nz = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            nz += key[i] != 0 ? 1 : 0;
+            if (key[i] != 0 && rank[i] < a.k) {
+                const float s = rq_key_score(key[i]);
+                const int64_t grow = a.row_offset + (int64_t)rq_key_index(key[i]);
+                os[rank[i]] = s;
+                orow[rank[i]] = grow;
+                if (ok) ok[rank[i]] = rq_make_key(s, (uint32_t)grow);
+                if (rank[i] == kk - 1) skth = key[i];
+            }
+        }
+        // number of non-empty keys: sum nz over the workgroup
+        if (nz) atomicAdd(&snz, nz);
+        __syncthreads();
+        have = snz < a.k ? snz : a.k;
+        kth = skth;
+    } else
     for (int j = 0; j < a.k; ++j) {
         const uint64_t wm = rq_wave_max_u64(best);
         if (lane == 0) wbest[j & 1][wave] = wm;
@@ -537,7 +601,6 @@ __global__ __launch_bounds__(256) void rq_final_fast_kernel(RqFinalFastArgs a) {
     }
     for (int j = have + tid; j < a.k; j += 256) { os[j] = 0.f; orow[j] = -1; if (ok) ok[j] = 0; }
     if (tid == 0) {
-        const float T = a.thr[q];
         int good;
         if (total > a.rmax) good = 0;                                   // bin list overflowed
         else if (T == -__builtin_huge_valf()) good = have >= kk;        // every bin was a candidate

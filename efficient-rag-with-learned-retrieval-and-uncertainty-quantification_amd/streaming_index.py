@@ -1,0 +1,562 @@
+"""Drop-in mirror of reference `rag_uq/streaming_index.py` with the dense path on MI355X.
+
+Same module-level names, constructor signatures, defaults and return conventions as the reference
+(Document :54-77, RetrievalResult :80-89, BM25Index :92-225, DenseIndex :228-373, HybridRetriever
+:376-560, StreamingIndex :563-686), so `experiments/run_evaluation.py:165-167`,
+`experiments/run_router_training.py:80-82` and `data/preprocessing/build_chroma_index.py:55-125`
+run unchanged against it.  What differs underneath:
+
+  * DenseIndex keeps the passage vectors as an fp16 matrix in HBM and answers `search` with an exact
+    cosine top-k computed by hand-written HIP kernels (librq_hip.so, include/rq.h) instead of
+    ChromaDB/HNSW; embeddings come from an in-process embedder instead of one Ollama HTTP request
+    per text.  There is no CPU fallback for this class.
+  * BM25Index restates rank-bm25's BM25Okapi (not installed here) over an inverted index, so adding
+    documents no longer rebuilds the whole model.  It stays on the CPU (BASELINE.json configs[4]).
+  * Batched entry points are added next to the single-query ones (`search_batch`,
+    `hybrid_search_batch`, `get_scores_for_router_batch`); the originals are thin wrappers.
+"""
+from __future__ import annotations
+
+import json
+import logging
+import math
+import os
+import pickle
+from collections import Counter
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Any, Dict, Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _native
+from .embedders import HashEmbedder, default_embedder
+
+logger = logging.getLogger(__name__)
+
+
+def _gpu_backend_available() -> bool:
+    """True when librq_hip.so loads and sees a device.  A missing library raises (loud), a missing
+    GPU only disables dense retrieval, like the reference's HAS_CHROMA switch (:31-37, :412-420)."""
+    return _native.device_count() > 0
+
+
+# =============================================================================================
+# records (reference :54-89)
+# =============================================================================================
+@dataclass
+class Document:
+    """A document for indexing."""
+    id: str
+    text: str
+    title: Optional[str] = None
+    metadata: Optional[Dict[str, Any]] = None
+
+    def to_dict(self) -> Dict[str, Any]:
+        return {"id": self.id, "text": self.text, "title": self.title or "", "metadata": self.metadata or {}}
+
+    @classmethod
+    def from_dict(cls, data: Dict[str, Any]) -> "Document":
+        return cls(id=data["id"], text=data["text"], title=data.get("title"), metadata=data.get("metadata"))
+
+
+@dataclass
+class RetrievalResult:
+    """Result from hybrid retrieval."""
+    doc_id: str
+    text: str
+    bm25_score: float
+    dense_score: float
+    hybrid_score: Optional[float] = None
+    title: Optional[str] = None
+    metadata: Optional[Dict[str, Any]] = None
+
+
+# =============================================================================================
+# sparse side (reference :92-225).  CPU, host logic.
+# =============================================================================================
+class BM25Index:
+    """BM25Okapi over an inverted index; same API, pickle layout and scores as the reference class.
+
+    Scoring restates rank-bm25 0.2.2 `BM25Okapi` (requirements.txt:8; not vendored, not installed):
+      idf(t)  = ln(N - n_t + 0.5) - ln(n_t + 0.5); negative idfs are replaced by 0.25 * mean(idf)
+      score   = sum over query tokens t (with repetition) of
+                idf(t) * f * (k1 + 1) / (f + k1 * (1 - b + b * dl / avgdl))
+    `search` keeps the reference's selection verbatim (:172-177): argsort, reversed, first top_k,
+    score > 0 only.
+    """
+
+    EPSILON = 0.25
+
+    def __init__(self, persist_path: Optional[str] = None, k1: float = 1.5, b: float = 0.75):
+        self.persist_path = Path(persist_path) if persist_path else None
+        self.k1 = k1
+        self.b = b
+        self.documents: Dict[str, Document] = {}
+        self.doc_ids: List[str] = []
+        self.tokenized_corpus: List[List[str]] = []
+        # inverted index: token -> (doc rows, term frequencies), appended in row order
+        self._post_rows: Dict[str, List[int]] = {}
+        self._post_tf: Dict[str, List[int]] = {}
+        self._doc_len: List[int] = []
+        self._total_len = 0
+        self._idf: Optional[Dict[str, float]] = None   # None = stale
+        if self.persist_path and self.persist_path.exists():
+            self._load()
+
+    @property
+    def bm25(self):
+        """The reference exposes the BM25Okapi object; callers only test it for None (:165)."""
+        return self if self.doc_ids else None
+
+    def _tokenize(self, text: str) -> List[str]:
+        return text.lower().split()
+
+    def _index_tokens(self, row: int, tokens: List[str]) -> None:
+        for tok, tf in Counter(tokens).items():
+            self._post_rows.setdefault(tok, []).append(row)
+            self._post_tf.setdefault(tok, []).append(tf)
+        self._doc_len.append(len(tokens))
+        self._total_len += len(tokens)
+        self._idf = None
+
+    def add_documents(self, documents: List[Document]) -> int:
+        new_count = 0
+        for doc in documents:
+            if doc.id in self.documents:
+                continue
+            self.documents[doc.id] = doc
+            self.doc_ids.append(doc.id)
+            toks = self._tokenize(doc.text)
+            self.tokenized_corpus.append(toks)
+            self._index_tokens(len(self.doc_ids) - 1, toks)
+            new_count += 1
+        if new_count:
+            logger.info(f"Added {new_count} documents to BM25 index. Total: {len(self.doc_ids)}")
+        if self.persist_path:
+            self._save()
+        return new_count
+
+    def _ensure_idf(self) -> Dict[str, float]:
+        if self._idf is not None:
+            return self._idf
+        n_docs = len(self.doc_ids)
+        idf: Dict[str, float] = {}
+        idf_sum = 0.0
+        negative: List[str] = []
+        for tok, rows in self._post_rows.items():   # insertion order = first-seen order, as BM25Okapi's nd dict
+            n_t = len(rows)
+            v = math.log(n_docs - n_t + 0.5) - math.log(n_t + 0.5)
+            idf[tok] = v
+            idf_sum += v
+            if v < 0:
+                negative.append(tok)
+        if idf:
+            eps = self.EPSILON * (idf_sum / len(idf))
+            for tok in negative:
+                idf[tok] = eps
+        self._idf = idf
+        return idf
+
+    def get_scores(self, tokenized_query: List[str]) -> np.ndarray:
+        n_docs = len(self.doc_ids)
+        scores = np.zeros(n_docs)
+        if n_docs == 0:
+            return scores
+        idf = self._ensure_idf()
+        avgdl = self._total_len / n_docs
+        doc_len = np.asarray(self._doc_len, dtype=np.float64)
+        for tok in tokenized_query:
+            rows = self._post_rows.get(tok)
+            if not rows:
+                continue
+            r = np.asarray(rows, dtype=np.int64)
+            f = np.asarray(self._post_tf[tok], dtype=np.float64)
+            w = idf.get(tok) or 0
+            scores[r] += w * (f * (self.k1 + 1) / (f + self.k1 * (1 - self.b + self.b * doc_len[r] / avgdl)))
+        return scores
+
+    def search(self, query: str, top_k: int = 10) -> List[Tuple[str, float]]:
+        if self.bm25 is None or not self.doc_ids:
+            return []
+        scores = self.get_scores(self._tokenize(query))
+        top_indices = np.argsort(scores)[::-1][:top_k]
+        return [(self.doc_ids[i], float(scores[i])) for i in top_indices if scores[i] > 0]
+
+    def get_document(self, doc_id: str) -> Optional[Document]:
+        return self.documents.get(doc_id)
+
+    def _save(self):
+        if self.persist_path is None:
+            return
+        self.persist_path.parent.mkdir(parents=True, exist_ok=True)
+        data = {
+            "documents": {k: v.to_dict() for k, v in self.documents.items()},
+            "doc_ids": self.doc_ids,
+            "tokenized_corpus": self.tokenized_corpus,
+            "k1": self.k1,
+            "b": self.b,
+        }
+        with open(self.persist_path, "wb") as f:
+            pickle.dump(data, f)
+
+    def _load(self):
+        if self.persist_path is None or not self.persist_path.exists():
+            return
+        with open(self.persist_path, "rb") as f:
+            data = pickle.load(f)   # a file this class (or the reference's twin) wrote
+        self.documents = {k: Document.from_dict(v) for k, v in data["documents"].items()}
+        self.doc_ids = data["doc_ids"]
+        self.tokenized_corpus = data["tokenized_corpus"]
+        self.k1 = data["k1"]
+        self.b = data["b"]
+        self._post_rows, self._post_tf, self._doc_len, self._total_len = {}, {}, [], 0
+        for row, toks in enumerate(self.tokenized_corpus):
+            self._index_tokens(row, toks)
+        logger.info(f"Loaded BM25 index with {len(self.doc_ids)} documents")
+
+    def __len__(self) -> int:
+        return len(self.doc_ids)
+
+
+# =============================================================================================
+# dense side (reference :228-373) -- the hot path
+# =============================================================================================
+class DenseIndex:
+    """Exact cosine top-k over fp16 passage vectors resident in MI355X HBM.
+
+    Signature and defaults follow reference :236-243.  `chroma_host` / `chroma_port` are accepted for
+    call compatibility and ignored (there is no service).  Keyword-only extras: `embedder`, `device`,
+    `metric`.  Construction raises when the GPU backend is unavailable, as the reference raises
+    ImportError without chromadb (:248-249).
+    """
+
+    def __init__(self, collection_name: str = "rag_documents", persist_directory: str = "./data/chroma_db",
+                 embedding_model: str = "nomic-embed-text", chroma_host: Optional[str] = None, chroma_port: int = 8000,
+                 *, embedder=None, device: int = 0, metric: str = "cosine", load_persisted: bool = True):
+        self.collection_name = collection_name
+        self.persist_directory = persist_directory
+        self.embedding_model = embedding_model
+        if chroma_host:
+            logger.info("chroma_host=%s ignored: the dense index is in-process on GPU %d", chroma_host, device)
+        if not _gpu_backend_available():
+            raise ImportError("a gfx950 GPU (librq_hip.so backend) is required for DenseIndex")
+        self.embedder = embedder if embedder is not None else default_embedder(embedding_model)
+        self.device = int(device)
+        self.metric = _native.METRIC_IP if metric in ("ip", "inner_product") else _native.METRIC_COSINE
+        self.dim: Optional[int] = None
+        self._index: Optional[_native.NativeIndex] = None
+        self._ids: List[str] = []
+        self._row_of: Dict[str, int] = {}
+        self._texts: List[str] = []
+        self._metas: List[Dict[str, Any]] = []
+        if load_persisted and persist_directory and self._files()[0].exists():
+            self._load()
+        logger.info(f"Initialized DenseIndex with collection '{collection_name}'")
+
+    # ---- embedding (reference :267-288) -----------------------------------------------------------
+    def _zero(self) -> List[float]:
+        return [0.0] * (self.dim or getattr(self.embedder, "dim", 768) or 768)
+
+    def _get_embedding(self, text: str) -> List[float]:
+        try:
+            return [float(v) for v in self.embedder.embed([text])[0]]
+        except Exception as e:   # reference :281-284: log, zero vector
+            logger.error(f"Embedding failed: {e}")
+            return self._zero()
+
+    def _get_embeddings_batch(self, texts: List[str]) -> List[List[float]]:
+        return self._embed_matrix(texts).tolist()
+
+    def _embed_matrix(self, texts: Sequence[str]) -> np.ndarray:
+        """One embedder call for the whole batch; on failure fall back to per-text calls so a bad text
+        degrades to a zero row instead of failing its neighbours."""
+        if not texts:
+            return np.zeros((0, self.dim or getattr(self.embedder, "dim", 768)), np.float32)
+        try:
+            v = np.asarray(self.embedder.embed(list(texts)), dtype=np.float32)
+            if v.ndim == 2 and v.shape[0] == len(texts):
+                return v
+            raise ValueError(f"embedder returned shape {v.shape}")
+        except Exception as e:
+            logger.error(f"Batch embedding failed ({e}); retrying one text at a time")
+            return np.asarray([self._get_embedding(t) for t in texts], dtype=np.float32)
+
+    # ---- build (reference :290-336) -----------------------------------------------------------------
+    def _ensure_index(self, dim: int) -> None:
+        if self._index is None:
+            self.dim = int(dim)
+            self._index = _native.NativeIndex(self.dim, self.device)
+        elif dim != self.dim:
+            raise ValueError(f"embedding dimension {dim} does not match the index ({self.dim})")
+
+    def add_documents(self, documents: List[Document], batch_size: int = 100) -> int:
+        # the reference fetches every stored id per call (:306); a hash table does the same filter
+        seen = set()
+        new_docs = []
+        for d in documents:
+            if d.id in self._row_of or d.id in seen:
+                continue
+            seen.add(d.id)
+            new_docs.append(d)
+        if not new_docs:
+            logger.info("No new documents to add")
+            return 0
+        total_added = 0
+        for i in range(0, len(new_docs), batch_size):
+            batch = new_docs[i:i + batch_size]
+            vecs = self._embed_matrix([d.text for d in batch])
+            self.add_vectors([d.id for d in batch], vecs, [d.text for d in batch],
+                             [{"title": d.title or "", **(d.metadata or {})} for d in batch])
+            total_added += len(batch)
+            logger.info(f"Indexed batch {i // batch_size + 1}, total: {total_added}/{len(new_docs)}")
+        return total_added
+
+    def add_vectors(self, ids: Sequence[str], vectors: np.ndarray, texts: Optional[Sequence[str]] = None,
+                    metadatas: Optional[Sequence[Dict[str, Any]]] = None) -> int:
+        """Append pre-computed embeddings (the `collection.add(embeddings=...)` of reference :326-331)."""
+        vectors = np.asarray(vectors, dtype=np.float32)
+        if vectors.ndim != 2 or vectors.shape[0] != len(ids):
+            raise ValueError("vectors must be [len(ids), dim]")
+        self._ensure_index(vectors.shape[1])
+        # cosine index: rows are unit-normalised before fp16 rounding (cosine is invariant, fp16 range is safe)
+        self._index.add_f32(vectors, normalize=self.metric == _native.METRIC_COSINE)
+        for j, doc_id in enumerate(ids):
+            self._row_of[doc_id] = len(self._ids)
+            self._ids.append(doc_id)
+            self._texts.append(texts[j] if texts is not None else "")
+            self._metas.append(dict(metadatas[j]) if metadatas is not None else {})
+        return len(ids)
+
+    # ---- query (reference :338-370) -------------------------------------------------------------------
+    def search_vectors(self, vectors: np.ndarray, top_k: int = 10) -> List[List[Tuple[str, float, str]]]:
+        vectors = np.atleast_2d(np.asarray(vectors, dtype=np.float32))
+        if self._index is None or len(self._ids) == 0 or top_k <= 0:
+            return [[] for _ in range(vectors.shape[0])]
+        if vectors.shape[1] != self.dim:
+            raise ValueError(f"query dimension {vectors.shape[1]} does not match the index ({self.dim})")
+        k = min(int(top_k), len(self._ids), _native.MAX_K)
+        scores, rows = self._index.search(vectors, k, self.metric)
+        out = []
+        for b in range(vectors.shape[0]):
+            out.append([(self._ids[r], float(s), self._texts[r]) for s, r in zip(scores[b], rows[b]) if r >= 0])
+        return out
+
+    def search_batch(self, queries: Sequence[str], top_k: int = 10) -> List[List[Tuple[str, float, str]]]:
+        if not queries:
+            return []
+        return self.search_vectors(self._embed_matrix(list(queries)), top_k)
+
+    def search(self, query: str, top_k: int = 10) -> List[Tuple[str, float, str]]:
+        """List of (doc_id, score, text), best first; score = cosine similarity (= 1 - Chroma distance)."""
+        return self.search_batch([query], top_k)[0]
+
+    def __len__(self) -> int:
+        return len(self._ids)
+
+    # ---- persistence (the Chroma persist directory of the reference) ------------------------------------
+    def _files(self) -> Tuple[Path, Path]:
+        base = Path(self.persist_directory) / self.collection_name
+        return Path(str(base) + ".docs.jsonl"), base
+
+    def save(self) -> None:
+        """rows -> <dir>/<collection>.f16/.meta (rq_save), ids/texts/metadata -> <collection>.docs.jsonl"""
+        docs_path, base = self._files()
+        docs_path.parent.mkdir(parents=True, exist_ok=True)
+        if self._index is not None:
+            self._index.save(str(base))
+        with open(docs_path, "w") as f:
+            for i, doc_id in enumerate(self._ids):
+                f.write(json.dumps({"id": doc_id, "text": self._texts[i], "metadata": self._metas[i]}) + "\n")
+
+    def _load(self) -> None:
+        docs_path, base = self._files()
+        if not Path(str(base) + ".meta").exists():
+            return
+        self._index = _native.NativeIndex.load(str(base), self.device)
+        self.dim = self._index.dim
+        with open(docs_path) as f:
+            for line in f:
+                rec = json.loads(line)
+                self._row_of[rec["id"]] = len(self._ids)
+                self._ids.append(rec["id"])
+                self._texts.append(rec.get("text", ""))
+                self._metas.append(rec.get("metadata", {}))
+        if len(self._ids) != len(self._index):
+            raise RuntimeError(f"persisted index is inconsistent: {len(self._ids)} ids vs {len(self._index)} rows")
+        logger.info(f"Loaded DenseIndex with {len(self._ids)} documents")
+
+
+# =============================================================================================
+# hybrid fusion (reference :376-560) -- pure host logic, kept semantically identical
+# =============================================================================================
+class HybridRetriever:
+    """Unified hybrid retrieval combining BM25 and dense retrieval (reference :376-560).
+
+    Extra keyword-only arguments: `dense_index` (inject a ready index), `embedder`, `device`.
+    """
+
+    def __init__(self, bm25_persist_path: str = "./data/bm25_index.pkl", chroma_persist_path: str = "./data/chroma_db",
+                 chroma_host: Optional[str] = None, embedding_model: str = "nomic-embed-text",
+                 *, dense_index=None, embedder=None, device: int = 0):
+        self.bm25_index = BM25Index(persist_path=bm25_persist_path)
+        if dense_index is not None:
+            self.dense_index = dense_index
+        elif _gpu_backend_available():
+            self.dense_index = DenseIndex(persist_directory=chroma_persist_path,
+                                          chroma_host=chroma_host or os.environ.get("CHROMA_HOST"),
+                                          embedding_model=embedding_model, embedder=embedder, device=device)
+        else:
+            self.dense_index = None
+            logger.warning("Dense retrieval disabled")   # reference :418-420
+        self.documents: Dict[str, Document] = {}
+
+    def add_documents(self, documents: List[Document], batch_size: int = 100) -> Dict[str, int]:
+        for doc in documents:
+            self.documents[doc.id] = doc
+        stats: Dict[str, int] = {}
+        # The reference tests `if self.bm25_index:` / `if self.dense_index:` (:442, :445); both classes
+        # define __len__, so an EMPTY index is falsy and never receives its first documents.  That is a
+        # defect, not a contract: here the test is `is not None` (DESIGN.md "deviations").
+        if self.bm25_index is not None:
+            stats["bm25_added"] = self.bm25_index.add_documents(documents)
+        if self.dense_index is not None:
+            stats["dense_added"] = self.dense_index.add_documents(documents, batch_size)
+        stats["total_documents"] = len(self.documents)
+        return stats
+
+    def bm25_search(self, query: str, top_k: int = 20) -> List[Tuple[str, float]]:
+        if self.bm25_index is None:
+            return []
+        return self.bm25_index.search(query, top_k)
+
+    def dense_search(self, query: str, top_k: int = 20) -> List[Tuple[str, float]]:
+        if self.dense_index is None:
+            return []
+        return [(doc_id, score) for doc_id, score, _ in self.dense_index.search(query, top_k)]
+
+    def dense_search_batch(self, queries: Sequence[str], top_k: int = 20) -> List[List[Tuple[str, float]]]:
+        if self.dense_index is None:
+            return [[] for _ in queries]
+        if hasattr(self.dense_index, "search_batch"):
+            res = self.dense_index.search_batch(list(queries), top_k)
+        else:
+            res = [self.dense_index.search(q, top_k) for q in queries]
+        return [[(d, s) for d, s, _ in r] for r in res]
+
+    def _fuse(self, bm25_list: List[Tuple[str, float]], dense_list: List[Tuple[str, float]], top_k: int) -> List[RetrievalResult]:
+        """Reference :485-523: union of both pools, ids unknown to `self.documents` dropped, missing
+        score 0.0, hybrid = (bm25/max_bm25 + dense/max_dense)/2 with `max(...) or 1`, stable sort desc.
+        The reference walks a Python set (arbitrary order); here the union is walked in first-seen
+        order (BM25 pool, then dense pool), one admissible instance of that order."""
+        bm25_results = dict(bm25_list)
+        dense_results = dict(dense_list)
+        results: List[RetrievalResult] = []
+        for doc_id in dict.fromkeys(list(bm25_results) + list(dense_results)):
+            doc = self.documents.get(doc_id)
+            if doc is None:
+                continue
+            results.append(RetrievalResult(doc_id=doc_id, text=doc.text, bm25_score=bm25_results.get(doc_id, 0.0),
+                                           dense_score=dense_results.get(doc_id, 0.0), title=doc.title, metadata=doc.metadata))
+        if results:
+            max_bm25 = max(r.bm25_score for r in results) or 1
+            max_dense = max(r.dense_score for r in results) or 1
+            for r in results:
+                r.hybrid_score = (r.bm25_score / max_bm25 + r.dense_score / max_dense) / 2
+            results.sort(key=lambda x: x.hybrid_score or 0, reverse=True)
+        return results[:top_k]
+
+    def hybrid_search(self, query: str, top_k: int = 10, retrieval_pool_size: int = 50) -> List[RetrievalResult]:
+        return self._fuse(self.bm25_search(query, retrieval_pool_size), self.dense_search(query, retrieval_pool_size), top_k)
+
+    def hybrid_search_batch(self, queries: Sequence[str], top_k: int = 10, retrieval_pool_size: int = 50) -> List[List[RetrievalResult]]:
+        """All dense pools from one GPU batch; BM25 and fusion per query on the host."""
+        dense = self.dense_search_batch(queries, retrieval_pool_size)
+        return [self._fuse(self.bm25_search(q, retrieval_pool_size), dense[i], top_k) for i, q in enumerate(queries)]
+
+    @staticmethod
+    def _router_arrays(results: List[RetrievalResult], num_passages: int):
+        bm25_scores = [r.bm25_score for r in results]
+        dense_scores = [r.dense_score for r in results]
+        doc_ids = [r.doc_id for r in results]
+        texts = [r.text for r in results]
+        pad = num_passages - len(results)
+        if pad > 0:
+            bm25_scores += [0.0] * pad
+            dense_scores += [0.0] * pad
+            doc_ids += [""] * pad
+            texts += [""] * pad
+        return bm25_scores, dense_scores, doc_ids, texts
+
+    def get_scores_for_router(self, query: str, num_passages: int = 20) -> Tuple[List[float], List[float], List[str], List[str]]:
+        return self._router_arrays(self.hybrid_search(query, top_k=num_passages), num_passages)
+
+    def get_scores_for_router_batch(self, queries: Sequence[str], num_passages: int = 20):
+        return [self._router_arrays(r, num_passages) for r in self.hybrid_search_batch(queries, top_k=num_passages)]
+
+    def __len__(self) -> int:
+        return len(self.documents)
+
+
+# =============================================================================================
+# streaming indexer + checkpoint (reference :563-686)
+# =============================================================================================
+class StreamingIndex:
+    """Resumable JSONL -> retriever feeder with the reference's checkpoint schema
+    {'last_offset', 'total_indexed', 'files_completed'} (:593-604)."""
+
+    def __init__(self, retriever: HybridRetriever, checkpoint_path: str = "./data/index_checkpoint.json", batch_size: int = 100):
+        self.retriever = retriever
+        self.checkpoint_path = Path(checkpoint_path)
+        self.batch_size = batch_size
+        self.progress = self._load_checkpoint()
+
+    def _load_checkpoint(self) -> Dict[str, Any]:
+        if self.checkpoint_path.exists():
+            with open(self.checkpoint_path) as f:
+                return json.load(f)
+        return {"last_offset": 0, "total_indexed": 0, "files_completed": []}
+
+    def _save_checkpoint(self):
+        self.checkpoint_path.parent.mkdir(parents=True, exist_ok=True)
+        with open(self.checkpoint_path, "w") as f:
+            json.dump(self.progress, f)
+
+    def _commit(self, batch: List[Document], offset: int) -> int:
+        self.retriever.add_documents(batch)
+        self.progress["last_offset"] = offset
+        self.progress["total_indexed"] += len(batch)
+        self._save_checkpoint()
+        return len(batch)
+
+    def stream_from_jsonl(self, jsonl_path: str, resume: bool = True) -> Iterator[int]:
+        path = Path(jsonl_path)
+        if not path.exists():
+            raise FileNotFoundError(f"Corpus file not found: {jsonl_path}")
+        start_offset = self.progress["last_offset"] if resume else 0
+        with open(path) as f:
+            for _ in range(start_offset):
+                f.readline()
+            batch: List[Document] = []
+            offset = start_offset
+            for line in f:
+                try:
+                    data = json.loads(line.strip())
+                    batch.append(Document(id=data["id"], text=data["text"], title=data.get("title"), metadata=data.get("metadata")))
+                except (json.JSONDecodeError, KeyError) as e:
+                    logger.warning(f"Skipping invalid line at offset {offset}: {e}")
+                offset += 1
+                if len(batch) >= self.batch_size:
+                    n = self._commit(batch, offset)
+                    logger.info(f"Indexed batch: {n} docs, total: {self.progress['total_indexed']}")
+                    yield n
+                    batch = []
+            if batch:
+                yield self._commit(batch, offset)
+        if jsonl_path not in self.progress["files_completed"]:
+            self.progress["files_completed"].append(jsonl_path)
+            self._save_checkpoint()
+        logger.info(f"Completed indexing {jsonl_path}")
+
+    def get_progress(self) -> Dict[str, Any]:
+        return {**self.progress, "retriever_size": len(self.retriever)}

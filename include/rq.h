@@ -63,7 +63,8 @@ int rq_index_reserve(rq_index* idx, int64_t n_rows);
  * The fp64 norm of the STORED row is computed on device and kept for exact scoring. */
 int rq_index_add_f16(rq_index* idx, const uint16_t* rows, int64_t n_rows);
 int rq_index_add_f32(rq_index* idx, const float* rows, int64_t n_rows, int normalize);
-/* Same, rows already in device memory of the index's GPU. */
+/* Same, rows already in device memory of the index's GPU.  The call first waits for ALL prior work on
+ * the device (the rows may come from any stream of the caller), then appends synchronously. */
 int rq_index_add_f16_device(rq_index* idx, const void* d_rows, int64_t n_rows);
 int rq_index_add_f32_device(rq_index* idx, const float* d_rows, int64_t n_rows, int normalize);
 /* Copy stored rows [row_begin, row_begin+n) back to the host as fp16 bit patterns [n][dim]. */
