@@ -44,7 +44,8 @@ def main() -> None:
     ap.add_argument("--rows", type=int, default=N_ROWS)
     ap.add_argument("--k", type=int, default=TOPK)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=2, help="caller streams the batches alternate over")
+    ap.add_argument("--pipeline", type=int, default=0, help="1: tail kernels on the library's internal stream")
     args = ap.parse_args()
 
     import numpy as np
@@ -81,6 +82,7 @@ def main() -> None:
     idx = nat.NativeIndex(DIM, local_rank)
     idx.reserve(max(n_local, 1))
     idx.set_row_offset(row_lo)
+    idx.set_option("pipeline", args.pipeline)
     for c in range(c_lo, c_hi):
         g = torch.Generator(device=dev)
         g.manual_seed(1235 + c)
@@ -114,6 +116,7 @@ def main() -> None:
             return
         r = pending["ring"]
         for s in streams:
+            idx.search_flush_device(s.cuda_stream)      # tails of earlier searches become ordered on s
             comm_stream.wait_stream(s)
         with torch.cuda.stream(comm_stream):
             dist.all_gather_into_tensor(gathered[r], ring[r])
@@ -214,7 +217,7 @@ def main() -> None:
         "dtype": "f16",
         "data": "synthetic",
         "config": {"workload": f"{n_total}x{DIM} fp16 corpus, batch-{B} queries, top-{k}, cosine, exact (certified) results",
-                   "rows_per_gpu": n_local, "streams": len(streams), "gather_every": GATHER_EVERY if use_comm else 0,
+                   "rows_per_gpu": n_local, "streams": len(streams), "pipeline": args.pipeline, "gather_every": GATHER_EVERY if use_comm else 0,
                    "parallelism": f"row-shard x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "rq_scan_kernel",

@@ -58,6 +58,7 @@ _SIGNATURES = {
                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     "rq_search_fixup_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rq_search_flush_device": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rq_merge_keys_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
     "rq_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
@@ -208,6 +209,9 @@ class NativeIndex:
         return _check(self._lib.rq_search_fixup_device(self._h, _ptr(d_queries), int(B), int(k), int(metric), _ptr(d_scores),
                                                        _ptr(d_rows), _ptr(d_keys), _ptr(d_status), C.c_void_p(stream)),
                       "rq_search_fixup_device")
+
+    def search_flush_device(self, stream: int = 0) -> None:
+        _check(self._lib.rq_search_flush_device(self._h, C.c_void_p(stream)), "rq_search_flush_device")
 
     # -- knobs / timing -----------------------------------------------------------------------
     def set_option(self, name: str, value: float) -> None:

@@ -67,6 +67,17 @@ struct Workspace {
     int* fix_status = nullptr;
 };
 
+// Per caller stream: two workspaces (alternating calls), an internal tail stream and the events that
+// order scan -> tail and tail -> reuse of the same workspace two calls later ("pipeline" option).
+struct StreamCtx {
+    Workspace w[2];
+    hipStream_t tail = nullptr;
+    hipEvent_t ev_scan[2] = {nullptr, nullptr};
+    hipEvent_t ev_tail[2] = {nullptr, nullptr};
+    bool tail_pending[2] = {false, false};
+    uint64_t calls = 0;
+};
+
 struct rq_index {
     int dim = 0, device = 0, cu_count = 256;
     int64_t n = 0, cap = 0, row_offset = 0;
@@ -78,9 +89,9 @@ struct rq_index {
     double* d_maxnorm = nullptr;   // device scalar, bits of the running max row norm
     double max_row_norm = 0.0;
     // options
-    int ring = 4, prefetch = 1, bin_tiles = 4, wg_per_cu = 3, nt = -1, slack_bins = -1, profile = 0, fast_tail = 1;
+    int ring = 4, prefetch = 4, bin_tiles = 4, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, fast_tail = 1, pipeline = 0;
     double eps = -1.0;
-    std::map<hipStream_t, Workspace> ws;
+    std::map<hipStream_t, StreamCtx> ctx;
     hipStream_t own_stream = nullptr;
     // host-call staging
     float* h_dq = nullptr; float* h_dscores = nullptr; int64_t* h_drows = nullptr; int* h_dstatus = nullptr;
@@ -140,10 +151,10 @@ static int grow(rq_index* idx, int64_t want_rows) {
     HIPCHK(hipMemsetAsync(nn + keep, 0, (size_t)(cap - keep) * sizeof(double), idx->own_stream));
     HIPCHK(hipMemsetAsync(ni + keep, 0, (size_t)(cap - keep) * sizeof(float), idx->own_stream));
     HIPCHK(hipStreamSynchronize(idx->own_stream));
-    if (idx->x) hipFree(idx->x);
-    if (idx->rownorm64) hipFree(idx->rownorm64);
-    if (idx->inv_norm) hipFree(idx->inv_norm);
-    if (idx->ones) { hipFree(idx->ones); idx->ones = nullptr; idx->ones_valid = 0; }
+    if (idx->x) (void)hipFree(idx->x);
+    if (idx->rownorm64) (void)hipFree(idx->rownorm64);
+    if (idx->inv_norm) (void)hipFree(idx->inv_norm);
+    if (idx->ones) { (void)hipFree(idx->ones); idx->ones = nullptr; idx->ones_valid = 0; }
     idx->x = nx; idx->rownorm64 = nn; idx->inv_norm = ni; idx->cap = cap;
     return RQ_OK;
 }
@@ -184,19 +195,27 @@ extern "C" rq_index* rq_index_create(int dim, int n_devices, const int* device_i
 
 static void free_ws(Workspace& w) {
     void* p[] = {w.qh, w.q32, w.qn, w.pooled, w.binkeys, w.cand, w.wgmax, w.binlist, w.bincount, w.thr, w.fix_q, w.fix_scores, w.fix_rows, w.fix_keys, w.fix_status};
-    for (void* q : p) if (q) hipFree(q);
+    for (void* q : p) if (q) (void)hipFree(q);
     w = Workspace();
 }
 
 extern "C" void rq_index_destroy(rq_index* idx) {
     if (!idx) return;
-    hipSetDevice(idx->device);
-    hipDeviceSynchronize();
-    for (auto& kv : idx->ws) free_ws(kv.second);
-    for (auto& ev : idx->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+    (void)hipSetDevice(idx->device);
+    (void)hipDeviceSynchronize();
+    for (auto& kv : idx->ctx) {
+        free_ws(kv.second.w[0]);
+        free_ws(kv.second.w[1]);
+        if (kv.second.tail) (void)hipStreamDestroy(kv.second.tail);
+        for (int p = 0; p < 2; ++p) {
+            if (kv.second.ev_scan[p]) (void)hipEventDestroy(kv.second.ev_scan[p]);
+            if (kv.second.ev_tail[p]) (void)hipEventDestroy(kv.second.ev_tail[p]);
+        }
+    }
+    for (auto& ev : idx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     void* p[] = {idx->x, idx->rownorm64, idx->inv_norm, idx->ones, idx->d_maxnorm, idx->h_dq, idx->h_dscores, idx->h_drows, idx->h_dstatus};
-    for (void* q : p) if (q) hipFree(q);
-    if (idx->own_stream) hipStreamDestroy(idx->own_stream);
+    for (void* q : p) if (q) (void)hipFree(q);
+    if (idx->own_stream) (void)hipStreamDestroy(idx->own_stream);
     delete idx;
 }
 
@@ -272,7 +291,7 @@ static int add_host_common(rq_index* idx, const void* rows, int64_t n_rows, bool
         if (e != hipSuccess) { rc = set_err(RQ_EHIP, "H2D copy failed: %s", hipGetErrorString(e)); break; }
         rc = add_device_common(idx, stage, m, is_f32, normalize);
     }
-    hipFree(stage);
+    (void)hipFree(stage);
     return rc;
 }
 extern "C" int rq_index_add_f16(rq_index* idx, const uint16_t* rows, int64_t n_rows) { return add_host_common(idx, rows, n_rows, false, 0); }
@@ -302,6 +321,7 @@ extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     else if (s == "eps") idx->eps = v;
     else if (s == "profile") idx->profile = (int)v;
     else if (s == "fast_tail") idx->fast_tail = (int)v;
+    else if (s == "pipeline") idx->pipeline = (int)v;
     else return set_err(RQ_EINVAL, "unknown option '%s'", name);
     return RQ_OK;
 }
@@ -317,6 +337,7 @@ extern "C" double rq_get_option(const rq_index* idx, const char* name) {
     if (s == "eps") return idx->eps < 0 ? RQ_EPS_DEFAULT : idx->eps;
     if (s == "profile") return idx->profile;
     if (s == "fast_tail") return idx->fast_tail;
+    if (s == "pipeline") return idx->pipeline;
     if (s == "cu_count") return idx->cu_count;
     if (s == "max_row_norm") return idx->max_row_norm;
     return NAN;
@@ -382,6 +403,19 @@ static int fill_empty(int B, int k, float* d_scores, int64_t* d_rows, uint64_t* 
     return RQ_OK;
 }
 
+// Make `s` wait for every tail still running on the internal tail stream of `s` (pipeline mode).
+static int flush_tails(rq_index* idx, hipStream_t s) {
+    auto it = idx->ctx.find(s);
+    if (it == idx->ctx.end()) return RQ_OK;
+    StreamCtx& c = it->second;
+    for (int p = 0; p < 2; ++p)
+        if (c.tail_pending[p]) {
+            HIPCHK(hipStreamWaitEvent(s, c.ev_tail[p], 0));
+            c.tail_pending[p] = false;
+        }
+    return RQ_OK;
+}
+
 // One pass of the pipeline for B queries.  nb < 0: exact scan (every bin re-scored, no corpus scan).
 static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metric, int nb, float* d_scores, int64_t* d_rows,
                         uint64_t* d_keys, int* d_status, hipStream_t s) {
@@ -399,7 +433,25 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     int rmax = 0;
     if (fast) { rmax = std::min(RQ_FAST_MAX_BINS, std::max(32, 2 * m)); rmax = (rmax + 7) / 8 * 8; }
     const int64_t ncand = fast ? (int64_t)rmax * binrows : (int64_t)nb * binrows;
-    Workspace& w = idx->ws[s];
+    StreamCtx& cx = idx->ctx[s];
+    const bool piped = fast && idx->pipeline != 0;
+    int par = 0;
+    if (piped) {
+        if (!cx.tail) {
+            // plain priority: a high-priority tail stream was measured to slow the scan it overlaps
+            HIPCHK(hipStreamCreateWithFlags(&cx.tail, hipStreamNonBlocking));
+            for (int p = 0; p < 2; ++p) {
+                HIPCHK(hipEventCreateWithFlags(&cx.ev_scan[p], hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&cx.ev_tail[p], hipEventDisableTiming));
+            }
+        }
+        par = (int)(cx.calls++ & 1);
+        // this workspace was last used two calls ago: its tail must have finished before it is overwritten
+        if (cx.tail_pending[par]) { HIPCHK(hipStreamWaitEvent(s, cx.ev_tail[par], 0)); cx.tail_pending[par] = false; }
+    } else {
+        if (int r = flush_tails(idx, s)) return r;   // order after anything still on the tail stream
+    }
+    Workspace& w = cx.w[par];
     if (int r = ensure_ws(idx, w, bpad, exact ? 64 : stride, exact ? 1 : m, ncand)) return r;
     const float* scale = idx->inv_norm;
     if (metric == RQ_METRIC_IP) { if (int r = ensure_ones(idx, s)) return r; scale = idx->ones; }
@@ -434,21 +486,28 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             if (prof) { HIPCHK(hipEventRecord(idx->events[idx->ev_used].second, s)); idx->ev_used++; }
         }
         if (fast) {
+            hipStream_t ts = s;
+            if (piped) {
+                HIPCHK(hipEventRecord(cx.ev_scan[par], s));
+                HIPCHK(hipStreamWaitEvent(cx.tail, cx.ev_scan[par], 0));
+                ts = cx.tail;
+            }
             RqCollectArgs ca;
             ca.pooled = w.pooled; ca.pooled_stride = w.pooled_stride; ca.nbins = nbins; ca.wgmax = w.wgmax;
             ca.wgmax_stride = RQ_WGMAX_STRIDE; ca.nwg = grid; ca.m = m; ca.rmax = rmax; ca.binlist = w.binlist;
             ca.bincount = w.bincount; ca.thr = w.thr;
-            HIPCHK(rq_collect_launch(ca, B, s));
+            HIPCHK(rq_collect_launch(ca, B, ts));
             RqRescoreListArgs rl;
             rl.x = idx->x; rl.q32 = w.q32; rl.qnorm64 = w.qn; rl.rownorm64 = idx->rownorm64; rl.binlist = w.binlist;
             rl.bincount = w.bincount; rl.rmax = rmax; rl.R = R; rl.metric = metric; rl.n_rows = idx->n; rl.cand = w.cand;
-            HIPCHK(rq_rescore_list_launch(rl, B, s));
+            HIPCHK(rq_rescore_list_launch(rl, B, ts));
             RqFinalFastArgs ff;
             ff.cand = w.cand; ff.bincount = w.bincount; ff.thr = w.thr; ff.rmax = rmax; ff.binrows = binrows; ff.qnorm64 = w.qn;
             ff.metric = metric; ff.eps = idx->eps < 0 ? RQ_EPS_DEFAULT : (float)idx->eps;
             ff.max_row_norm = (float)(idx->max_row_norm * (1.0 + 1e-6)); ff.k = k; ff.row_offset = idx->row_offset;
             ff.n_rows = idx->n; ff.out_scores = d_scores; ff.out_rows = d_rows; ff.out_keys = d_keys; ff.out_status = d_status;
-            HIPCHK(rq_final_fast_launch(ff, B, s));
+            HIPCHK(rq_final_fast_launch(ff, B, ts));
+            if (piped) { HIPCHK(hipEventRecord(cx.ev_tail[par], cx.tail)); cx.tail_pending[par] = true; }
             return RQ_OK;
         }
         HIPCHK(rq_select_bins_launch(w.pooled, w.pooled_stride, nbins, B, m, w.binkeys, s));
@@ -485,12 +544,19 @@ extern "C" int rq_search_device(rq_index* idx, const float* d_queries, int B, in
     return run_pipeline(idx, d_queries, B, k, metric, nb_default(idx, k), d_scores, d_rows, d_keys, d_status, (hipStream_t)stream);
 }
 
+extern "C" int rq_search_flush_device(rq_index* idx, void* stream) {
+    if (!idx) return set_err(RQ_EINVAL, "null index");
+    if (int r = use_device(idx)) return r;
+    return flush_tails(idx, (hipStream_t)stream);
+}
+
 extern "C" int rq_search_fixup_device(rq_index* idx, const float* d_queries, int B, int k, int metric, float* d_scores,
                                       int64_t* d_rows, uint64_t* d_keys, int* d_status, void* stream) {
     if (int r = check_search_args(idx, d_queries, B, k, metric, d_scores, d_rows)) return r;
     if (!d_status) return set_err(RQ_EINVAL, "d_status is required");
     if (int r = use_device(idx)) return r;
     hipStream_t s = (hipStream_t)stream;
+    if (int r = flush_tails(idx, s)) return r;
     std::vector<int> st((size_t)B);
     HIPCHK(hipMemcpyAsync(st.data(), d_status, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -498,7 +564,7 @@ extern "C" int rq_search_fixup_device(rq_index* idx, const float* d_queries, int
     for (int q = 0; q < B; ++q) if (st[q] != 0) bad.push_back(q);
     if (bad.empty()) return 0;
     const int repaired = (int)bad.size();
-    Workspace& w = idx->ws[s];
+    Workspace& w = idx->ctx[s].w[0];
     const int fb = (int)bad.size();
     if (fb > w.fix_bcap || k > w.fix_k) {
         const int nb_ = std::max(fb, w.fix_bcap), nk = std::max(k, w.fix_k);

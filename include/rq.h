@@ -82,6 +82,11 @@ int rq_search(rq_index* idx, const float* queries, int B, int k, int metric, flo
  * Calls on different streams may overlap; each stream has its own workspace. */
 int rq_search_device(rq_index* idx, const float* d_queries, int B, int k, int metric, float* d_scores, int64_t* d_rows,
                      uint64_t* d_keys, int* d_status, void* stream);
+/* With option "pipeline" = 1 the tail of a search (bin collection, fp64 re-score, final top-k) runs on an
+ * internal stream so that the next corpus scan on `stream` starts at once; results of earlier
+ * rq_search_device calls are then ordered on `stream` only after this call (rq_search_fixup_device
+ * implies it). */
+int rq_search_flush_device(rq_index* idx, void* stream);
 /* Synchronises `stream`, re-runs the queries whose d_status is non-zero with wider candidate sets /
  * the exact scan, patches d_scores/d_rows/d_keys/d_status in place.  Returns the number repaired. */
 int rq_search_fixup_device(rq_index* idx, const float* d_queries, int B, int k, int metric, float* d_scores, int64_t* d_rows,
@@ -94,7 +99,9 @@ int rq_merge_keys_device(const uint64_t* d_keys_in, int n_per_query, int B, int 
 
 /* Tuning / test hooks: "ring" (LDS stages 3..6), "bin_tiles" (1,2,4: bin = 4*bin_tiles rows),
  * "wg_per_cu", "nt" (non-temporal corpus loads: 0, 1, -1 = auto), "slack_bins" (extra bins beyond k, -1 = auto),
- * "eps" (certificate bound, <0 = derived default), "profile" (record HIP events around every scan launch). */
+ * "eps" (certificate bound, <0 = derived default), "profile" (record HIP events around every scan launch),
+ * "prefetch" (LDS fragments read ahead of their MFMAs: 1, 4, 6, 12), "fast_tail" (0 = generic sorted tail),
+ * "pipeline" (see rq_search_flush_device). */
 int rq_set_option(rq_index* idx, const char* name, double value);
 double rq_get_option(const rq_index* idx, const char* name);
 

@@ -95,6 +95,7 @@ def run(tag, iters=40, nstreams=1, k=10):
     t0 = time.perf_counter()
     for i in range(iters):
         go(i)
+    for st_ in streams: idx.search_flush_device(st_.cuda_stream)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
     st = outs[0][3]
@@ -105,13 +106,18 @@ def run(tag, iters=40, nstreams=1, k=10):
     log(f"[perf] {tag}: scan {scan_us:8.1f} us  {gbs:7.1f} GB/s ({gbs/8000:.1%} of 8 TB/s)   end-to-end {dt*1e6:8.1f} us/batch  {B/dt:9.0f} q/s  uncertified={bad}")
     res.append(dict(tag=tag, scan_us=scan_us, gbs=gbs, e2e_us=dt * 1e6, qps=B / dt, uncertified=bad))
 
-for ring, pf, wg in [(4, 1, 3), (4, 4, 2), (6, 12, 2)]:
+for ring, pf, wg in [(4, 1, 3), (4, 4, 2), (6, 12, 2), (5, 6, 2)]:
     idx.set_option("ring", ring); idx.set_option("prefetch", pf); idx.set_option("wg_per_cu", wg); idx.set_option("nt", 1)
-    for ns in (1, 2):
-        run(f"ring={ring} pf={pf} wg/cu={wg} streams={ns} k=10", nstreams=ns)
-idx.set_option("ring", 4); idx.set_option("prefetch", 1); idx.set_option("wg_per_cu", 3)
+    for ns, pipe in ((1, 0), (2, 0), (1, 1), (2, 1)):
+        idx.set_option("pipeline", pipe)
+        run(f"ring={ring} pf={pf} wg/cu={wg} streams={ns} pipeline={pipe} k=10", nstreams=ns)
+        for st_ in streams: idx.search_flush_device(st_.cuda_stream)
+        torch.cuda.synchronize()
+idx.set_option("ring", 4); idx.set_option("prefetch", 4); idx.set_option("wg_per_cu", 2); idx.set_option("pipeline", 1)
 for kk in (1, 50, 100):
-    run(f"default streams=2 k={kk}", nstreams=2, k=kk)
+    run(f"default pipeline streams=1 k={kk}", nstreams=1, k=kk)
+for st_ in streams: idx.search_flush_device(st_.cuda_stream)
+torch.cuda.synchronize(); idx.set_option("pipeline", 0)
 idx.set_option("fast_tail", 0); run("generic tail streams=2 k=10", nstreams=2); idx.set_option("fast_tail", 1)
 out["perf"] = res
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
