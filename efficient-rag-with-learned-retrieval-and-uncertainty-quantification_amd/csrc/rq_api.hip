@@ -58,6 +58,9 @@ struct Workspace {
     int* binlist = nullptr;       // [bcap][RQ_FAST_MAX_BINS]
     int* bincount = nullptr;      // [bcap]
     float* thr = nullptr;         // [bcap]
+    int* done = nullptr;          // [bcap] fused tail: workgroups of the query that have finished
+    int* ovf = nullptr;           // [bcap] fused tail: a workgroup found more bins than it could hold
+    bool counters_dirty = true;   // bincount/done/ovf must be zeroed before the next fused-tail launch
     // staging for rq_search_fixup_device
     int fix_bcap = 0, fix_k = 0;
     float* fix_q = nullptr;
@@ -89,7 +92,7 @@ struct rq_index {
     double* d_maxnorm = nullptr;   // device scalar, bits of the running max row norm
     double max_row_norm = 0.0;
     // options
-    int ring = 4, prefetch = 4, bin_tiles = 4, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, fast_tail = 1, pipeline = 0;
+    int ring = 4, prefetch = 4, bin_tiles = 4, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, fast_tail = 1, pipeline = 0, fused_tail = 1, tail_stop = 0;
     double eps = -1.0;
     std::map<hipStream_t, StreamCtx> ctx;
     hipStream_t own_stream = nullptr;
@@ -194,7 +197,7 @@ extern "C" rq_index* rq_index_create(int dim, int n_devices, const int* device_i
 }
 
 static void free_ws(Workspace& w) {
-    void* p[] = {w.qh, w.q32, w.qn, w.pooled, w.binkeys, w.cand, w.wgmax, w.binlist, w.bincount, w.thr, w.fix_q, w.fix_scores, w.fix_rows, w.fix_keys, w.fix_status};
+    void* p[] = {w.qh, w.q32, w.qn, w.pooled, w.binkeys, w.cand, w.wgmax, w.binlist, w.bincount, w.thr, w.done, w.ovf, w.fix_q, w.fix_scores, w.fix_rows, w.fix_keys, w.fix_status};
     for (void* q : p) if (q) (void)hipFree(q);
     w = Workspace();
 }
@@ -322,6 +325,8 @@ extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     else if (s == "profile") idx->profile = (int)v;
     else if (s == "fast_tail") idx->fast_tail = (int)v;
     else if (s == "pipeline") idx->pipeline = (int)v;
+    else if (s == "fused_tail") idx->fused_tail = (int)v;
+    else if (s == "tail_stop") idx->tail_stop = (int)v;
     else return set_err(RQ_EINVAL, "unknown option '%s'", name);
     return RQ_OK;
 }
@@ -338,6 +343,7 @@ extern "C" double rq_get_option(const rq_index* idx, const char* name) {
     if (s == "profile") return idx->profile;
     if (s == "fast_tail") return idx->fast_tail;
     if (s == "pipeline") return idx->pipeline;
+    if (s == "fused_tail") return idx->fused_tail;
     if (s == "cu_count") return idx->cu_count;
     if (s == "max_row_norm") return idx->max_row_norm;
     return NAN;
@@ -365,6 +371,9 @@ static int ensure_ws(rq_index* idx, Workspace& w, int bpad, int64_t stride, int6
         if (int r = ensure(w.binlist, 0, (size_t)bcap * RQ_FAST_MAX_BINS)) return r;
         if (int r = ensure(w.bincount, 0, (size_t)bcap)) return r;
         if (int r = ensure(w.thr, 0, (size_t)bcap)) return r;
+        if (int r = ensure(w.done, 0, (size_t)bcap)) return r;
+        if (int r = ensure(w.ovf, 0, (size_t)bcap)) return r;
+        w.counters_dirty = true;
     }
     if (regrow_b || stride > w.pooled_stride) {
         const int64_t st = std::max(stride, w.pooled_stride);
@@ -456,10 +465,23 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     const float* scale = idx->inv_norm;
     if (metric == RQ_METRIC_IP) { if (int r = ensure_ones(idx, s)) return r; scale = idx->ones; }
 
-    HIPCHK(rq_prep_queries_launch(d_q, idx->dim, B, bpad, w.qh, w.q32, w.qn, w.bincount, s));
+    const bool fused = fast && idx->fused_tail != 0;
+    if (fused) {
+        if (w.counters_dirty) {   // first use of this workspace, or the three-kernel tail ran on it
+            HIPCHK(hipMemsetAsync(w.bincount, 0, (size_t)w.bcap * sizeof(int), s));
+            HIPCHK(hipMemsetAsync(w.done, 0, (size_t)w.bcap * sizeof(int), s));
+            HIPCHK(hipMemsetAsync(w.ovf, 0, (size_t)w.bcap * sizeof(int), s));
+            w.counters_dirty = false;
+        }
+    }
+    // unit-norm fp16 query fragments for the scan (+ padded fp32 queries / fp64 norms for the non-fused tails)
+    HIPCHK(rq_prep_queries_launch(d_q, idx->dim, B, bpad, w.qh, w.q32, w.qn, fused ? nullptr : w.bincount, s));
+    if (!fused) w.counters_dirty = true;
     const int grid = (int)std::min<int64_t>(std::min<int64_t>(nquads, RQ_WGMAX_STRIDE), (int64_t)idx->cu_count * idx->wg_per_cu);
     if (!exact) {
-        const bool nt = idx->nt < 0 ? (idx->n * (int64_t)(RQ_DPAD * 2) > ((int64_t)160 << 20)) : idx->nt != 0;
+        // non-temporal loads only for shards that cannot stay in the 256 MiB Infinity Cache between two scans
+        // (measured: 192 MB shard 36 us with default policy vs 39 us nt; 1.5 GB shard 250 us nt vs 285 us default)
+        const bool nt = idx->nt < 0 ? (idx->n * (int64_t)(RQ_DPAD * 2) > ((int64_t)208 << 20)) : idx->nt != 0;
         for (int blk = 0; blk < bpad / 64; ++blk) {
             RqScanArgs a;
             a.x = idx->x;
@@ -472,7 +494,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             a.nq_valid = std::min(64, B - blk * 64);
             a.wgmax = w.wgmax + (size_t)blk * 64 * RQ_WGMAX_STRIDE;
             a.wgmax_stride = RQ_WGMAX_STRIDE;
-            const bool prof = idx->profile && idx->ev_used < 16384;
+            const bool prof = idx->profile == 1 && idx->ev_used < 16384;
             if (prof) {
                 if (idx->ev_used == idx->events.size()) {
                     hipEvent_t e0, e1;
@@ -491,6 +513,33 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
                 HIPCHK(hipEventRecord(cx.ev_scan[par], s));
                 HIPCHK(hipStreamWaitEvent(cx.tail, cx.ev_scan[par], 0));
                 ts = cx.tail;
+            }
+            if (fused) {
+                RqTailArgs ta;
+                ta.q = d_q; ta.dim = idx->dim; ta.x = idx->x; ta.rownorm64 = idx->rownorm64; ta.n_rows = idx->n;
+                ta.pooled = w.pooled; ta.pooled_stride = w.pooled_stride; ta.nbins = nbins;
+                ta.wgmax = w.wgmax; ta.wgmax_stride = RQ_WGMAX_STRIDE; ta.nwg = grid;
+                ta.m = m; ta.rmax = rmax; ta.R = R; ta.metric = metric; ta.k = k;
+                ta.eps = idx->eps < 0 ? RQ_EPS_DEFAULT : (float)idx->eps;
+                ta.max_row_norm = (float)(idx->max_row_norm * (1.0 + 1e-6)); ta.row_offset = idx->row_offset;
+                ta.cand = w.cand; ta.bincount = w.bincount; ta.done = w.done; ta.ovf = w.ovf;
+                ta.out_scores = d_scores; ta.out_rows = d_rows; ta.out_keys = d_keys; ta.out_status = d_status;
+                ta.stop_after = idx->tail_stop;
+                if (idx->tail_stop) w.counters_dirty = true;   // a truncated tail does not reset its counters
+                const bool tprof = idx->profile == 2 && idx->ev_used < 16384;   // profile = 2: time the tail instead of the scan
+                if (tprof) {
+                    if (idx->ev_used == idx->events.size()) {
+                        hipEvent_t e0, e1;
+                        HIPCHK(hipEventCreate(&e0));
+                        HIPCHK(hipEventCreate(&e1));
+                        idx->events.push_back({e0, e1});
+                    }
+                    HIPCHK(hipEventRecord(idx->events[idx->ev_used].first, ts));
+                }
+                HIPCHK(rq_tail_launch(ta, B, ts));
+                if (tprof) { HIPCHK(hipEventRecord(idx->events[idx->ev_used].second, ts)); idx->ev_used++; }
+                if (piped) { HIPCHK(hipEventRecord(cx.ev_tail[par], cx.tail)); cx.tail_pending[par] = true; }
+                return RQ_OK;
             }
             RqCollectArgs ca;
             ca.pooled = w.pooled; ca.pooled_stride = w.pooled_stride; ca.nbins = nbins; ca.wgmax = w.wgmax;

@@ -52,3 +52,20 @@ __host__ __device__ static inline int64_t rq_bin_row(int64_t bin, int R, int j /
     const int tt = j >> 2, i = j & 3;
     return quad * 64 + 16 * (u * R + tt) + 4 * kg + i;
 }
+
+#ifdef __HIPCC__
+__device__ __forceinline__ double rq_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;   // identical in every lane (xor butterfly)
+}
+__device__ __forceinline__ float rq_sanitize(float f) { return (f != f) ? -__builtin_huge_valf() : f; }
+__device__ __forceinline__ uint64_t rq_wave_max_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+#endif

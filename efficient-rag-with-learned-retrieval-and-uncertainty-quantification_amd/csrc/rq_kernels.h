@@ -100,6 +100,22 @@ struct RqFinalFastArgs {
 };
 hipError_t rq_final_fast_launch(const RqFinalFastArgs& a, int B, hipStream_t stream);
 
+// Fused tail: threshold + bin collection + exact re-score + final top-k + certificate in one launch.
+struct RqTailArgs {
+    const float* q; int dim;                       // raw fp32 queries [B][dim]
+    const void* x; const double* rownorm64; int64_t n_rows;
+    const float* pooled; int64_t pooled_stride; int64_t nbins;
+    const float* wgmax; int wgmax_stride; int nwg;
+    int m, rmax, R, metric, k;
+    float eps, max_row_norm;
+    int64_t row_offset;
+    uint64_t* cand;                                // [B][rmax*4R]
+    int* bincount; int* done; int* ovf;            // [B] each, zero before the launch, reset by the kernel
+    float* out_scores; int64_t* out_rows; uint64_t* out_keys; int* out_status;
+    int stop_after;                                // development: 0 = full kernel, 1..4 = return after phase A..D
+};
+hipError_t rq_tail_launch(const RqTailArgs& a, int B, hipStream_t stream);
+
 // Merge G sorted key lists per query (cross-shard): in [B][G*k] -> top-k scores/rows/keys.
 hipError_t rq_merge_keys_launch(const uint64_t* keys, int n_per_query, int B, int k, float* out_scores, int64_t* out_rows,
                                 uint64_t* out_keys, hipStream_t stream);

@@ -49,16 +49,7 @@ __global__ __launch_bounds__(256, OCC) void rq_scan_kernel(RqScanArgs a) {
     const int kg = lane >> 4;          // k-group of the MFMA operand / row group of the result
     const int r16 = lane & 15;         // corpus row inside the tile (A operand), query inside the wave (D)
 
-    // ---- query fragments: B[k = 8*kg + j][col = r16] of k-step s  ==  qh[16*wave + r16][32*s + 8*kg + j]
-    rq_half8 qf[24];
-    {
-        const rq_half8* qsrc = (const rq_half8*)(a.qh + (size_t)(16 * wave + r16) * RQ_DPAD + 8 * kg);
-#pragma unroll
-        for (int s = 0; s < 24; ++s) qf[s] = qsrc[4 * s];
-#pragma unroll
-        for (int s = 0; s < 24; ++s) asm volatile("" : "+v"(qf[s]));   // loads retired before the DMA stream starts
-    }
-
+    // (query fragments are built after the DMA prologue has been issued, see below)
     // ---- per-lane DMA source offsets: LDS chunk p = 64*j + lane of a stage holds
     //      row r = p / 48, source chunk c = (p % 48) ^ r   (r < 16, XOR stays inside a 16-chunk group)
     unsigned voff[3];
@@ -103,6 +94,17 @@ __global__ __launch_bounds__(256, OCC) void rq_scan_kernel(RqScanArgs a) {
     int cslot = 0;   // slot of the stage being consumed
     const float NEG_INF = -__builtin_huge_valf();
     float wmax = NEG_INF;   // best pooled value this lane has produced (feeds the pass-2 threshold)
+
+    // ---- query fragments: B[k = 8*kg + j][col = r16] of k-step s == qh[16*wave + r16][32*s + 8*kg + j]
+    //      (unit-norm fp16 queries written by rq_prep_queries_kernel); loaded while the first stages are in flight
+    rq_half8 qf[24];
+    {
+        const rq_half8* qsrc = (const rq_half8*)(a.qh + (size_t)(16 * wave + r16) * RQ_DPAD + 8 * kg);
+#pragma unroll
+        for (int s = 0; s < 24; ++s) qf[s] = qsrc[4 * s];
+#pragma unroll
+        for (int s = 0; s < 24; ++s) asm volatile("" : "+v"(qf[s]));   // ordinary loads retired before the main loop
+    }
 
     for (int lq = 0; lq < nloc; ++lq) {
         const int64_t quad = (int64_t)b + (int64_t)lq * G;

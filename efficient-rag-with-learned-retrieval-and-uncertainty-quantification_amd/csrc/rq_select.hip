@@ -7,16 +7,12 @@
 // order = (fp32 score desc, row asc).
 #include "rq_device.h"
 #include "rq_kernels.h"
+#include "rq_final_body.h"
 
 // --------------------------------------------------------------------------------------------
 // small helpers
 // --------------------------------------------------------------------------------------------
-__device__ __forceinline__ double rq_wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;   // identical in every lane (xor butterfly)
-}
-__device__ __forceinline__ float rq_sanitize(float f) { return (f != f) ? -__builtin_huge_valf() : f; }
+// rq_wave_sum / rq_sanitize / rq_wave_max_u64: rq_device.h
 
 // --------------------------------------------------------------------------------------------
 // row norms: one wave per row, lane l owns elements p*256 + 4*l + e (p < 3, e < 4)
@@ -142,7 +138,7 @@ __global__ __launch_bounds__(256) void rq_prep_queries_kernel(const float* q, in
     if ((tid & 63) == 0) part[tid >> 6] = acc;
     __syncthreads();
     const double nrm = sqrt((part[0] + part[1]) + (part[2] + part[3]));
-    if (tid == 0 && qi < B) { qnorm64[qi] = nrm; bincount[qi] = 0; }
+    if (tid == 0 && qi < B) { qnorm64[qi] = nrm; if (bincount) bincount[qi] = 0; }
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
         const int i = p * 256 + tid;
@@ -491,127 +487,17 @@ hipError_t rq_rescore_list_launch(const RqRescoreListArgs& a, int B, hipStream_t
     return hipGetLastError();
 }
 
-__device__ __forceinline__ uint64_t rq_wave_max_u64(uint64_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)v, off, 64);
-        v = o > v ? o : v;
-    }
-    return v;
-}
 
-// One 256-thread workgroup per query: <= 4096 candidate keys in registers, k rounds of "extract the maximum".
+// One 256-thread workgroup per query; the selection itself is rq_final_body.h (shared with the fused tail).
 __global__ __launch_bounds__(256) void rq_final_fast_kernel(RqFinalFastArgs a) {
-    __shared__ uint64_t wbest[2][4];
-    __shared__ uint64_t skeys[1024];
-    __shared__ uint64_t skth;
-    __shared__ int snz;
-    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t kk = a.k < a.n_rows ? a.k : a.n_rows;
-    const double qn = a.qnorm64[q];
-    const float T = a.thr[q];
-    float* os = a.out_scores + (int64_t)q * a.k;
-    int64_t* orow = a.out_rows + (int64_t)q * a.k;
-    uint64_t* ok = a.out_keys ? a.out_keys + (int64_t)q * a.k : nullptr;
-    if (qn == 0.0) {   // every score is exactly 0: rows 0 .. kk-1 (score desc, row asc)
-        for (int j = tid; j < a.k; j += 256) {
-            const bool v = j < kk;
-            os[j] = 0.f;
-            orow[j] = v ? a.row_offset + j : -1;
-            if (ok) ok[j] = v ? rq_make_key(0.f, (uint32_t)(a.row_offset + j)) : 0;
-        }
-        if (tid == 0) a.out_status[q] = 0;
-        return;
-    }
-    const int total = a.bincount[q];
-    const int cnt = total < a.rmax ? total : a.rmax;
-    const int n = cnt * a.binrows;
-    const uint64_t* c = a.cand + (int64_t)q * a.rmax * a.binrows;
-    uint64_t key[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { const int j = i * 256 + tid; key[i] = j < n ? c[j] : 0; }
-    uint64_t best = 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) best = key[i] > best ? key[i] : best;
-    int have = 0;
-    uint64_t kth = 0;
-    if (n <= 1024) {
-        // small candidate set: rank every key against all others (LDS broadcast reads), write by rank
-        if (tid == 0) { skth = 0; snz = 0; }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) skeys[i * 256 + tid] = key[i];
-        __syncthreads();
-        int rank[4] = {0, 0, 0, 0};
-        // keys are laid out i*256 + tid: only the first ceil(n/256) registers of a thread can be non-empty
-        if (n <= 256) {
-#pragma unroll 4
-            for (int j = 0; j < n; ++j) rank[0] += skeys[j] > key[0] ? 1 : 0;
-        } else if (n <= 512) {
-#pragma unroll 4
-            for (int j = 0; j < n; ++j) { const uint64_t o = skeys[j]; rank[0] += o > key[0] ? 1 : 0; rank[1] += o > key[1] ? 1 : 0; }
-        } else {
-#pragma unroll 2
-            for (int j = 0; j < n; ++j) {
-                const uint64_t o = skeys[j];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) rank[i] += o > key[i] ? 1 : 0;
-            }
-        }
-        int nz = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            nz += key[i] != 0 ? 1 : 0;
-            if (key[i] != 0 && rank[i] < a.k) {
-                const float s = rq_key_score(key[i]);
-                const int64_t grow = a.row_offset + (int64_t)rq_key_index(key[i]);
-                os[rank[i]] = s;
-                orow[rank[i]] = grow;
-                if (ok) ok[rank[i]] = rq_make_key(s, (uint32_t)grow);
-                if (rank[i] == kk - 1) skth = key[i];
-            }
-        }
-        // number of non-empty keys: sum nz over the workgroup
-        if (nz) atomicAdd(&snz, nz);
-        __syncthreads();
-        have = snz < a.k ? snz : a.k;
-        kth = skth;
-    } else
-    for (int j = 0; j < a.k; ++j) {
-        const uint64_t wm = rq_wave_max_u64(best);
-        if (lane == 0) wbest[j & 1][wave] = wm;
-        __syncthreads();
-        uint64_t win = wbest[j & 1][0];
-#pragma unroll
-        for (int w2 = 1; w2 < 4; ++w2) win = wbest[j & 1][w2] > win ? wbest[j & 1][w2] : win;
-        if (win == 0) break;   // uniform: candidates exhausted
-        have = j + 1;
-        kth = win;
-        if (tid == 0) {
-            const float s = rq_key_score(win);
-            const int64_t grow = a.row_offset + (int64_t)rq_key_index(win);
-            os[j] = s;
-            orow[j] = grow;
-            if (ok) ok[j] = rq_make_key(s, (uint32_t)grow);
-        }
-        if (best == win) {   // keys are unique: exactly one thread owns the winner
-            best = 0;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { if (key[i] == win) key[i] = 0; best = key[i] > best ? key[i] : best; }
-        }
-    }
-    for (int j = have + tid; j < a.k; j += 256) { os[j] = 0.f; orow[j] = -1; if (ok) ok[j] = 0; }
-    if (tid == 0) {
-        int good;
-        if (total > a.rmax) good = 0;                                   // bin list overflowed
-        else if (T == -__builtin_huge_valf()) good = have >= kk;        // every bin was a candidate
-        else if (have < kk) good = 0;
-        else {
-            const double bound = a.metric == 0 ? (double)T + (double)a.eps
-                                               : ((double)T + (double)a.eps * (double)a.max_row_norm) * qn * (1.0 + 1e-6);
-            good = (float)bound < rq_key_score(kth);
-        }
-        a.out_status[q] = good ? 0 : 1;
-    }
+    __shared__ RqFinalLds lds;
+    const int q = blockIdx.x;
+    RqFinalCore c;
+    c.cand = a.cand + (int64_t)q * a.rmax * a.binrows; c.rmax = a.rmax; c.binrows = a.binrows; c.metric = a.metric; c.eps = a.eps;
+    c.max_row_norm = a.max_row_norm; c.k = a.k; c.row_offset = a.row_offset; c.n_rows = a.n_rows;
+    c.out_scores = a.out_scores + (int64_t)q * a.k; c.out_rows = a.out_rows + (int64_t)q * a.k;
+    c.out_keys = a.out_keys ? a.out_keys + (int64_t)q * a.k : nullptr; c.out_status = a.out_status + q;
+    rq_final_body<false>(c, a.bincount[q], 0, a.thr[q], a.qnorm64[q], lds);
 }
 hipError_t rq_final_fast_launch(const RqFinalFastArgs& a, int B, hipStream_t stream) {
     if (a.k < 1 || a.k > RQ_FAST_MAX_K || a.rmax * a.binrows > 4096) return hipErrorInvalidValue;
