@@ -60,7 +60,7 @@ struct Workspace {
     float* thr = nullptr;         // [bcap]
     int* done = nullptr;          // [bcap] fused tail: workgroups of the query that have finished
     int* ovf = nullptr;           // [bcap] fused tail: a workgroup found more bins than it could hold
-    bool counters_dirty = true;   // bincount/done/ovf must be zeroed before the next fused-tail launch
+    bool bincount_zero = false, done_zero = false, ovf_zero = false;   // counters known to be all zero right now
     // staging for rq_search_fixup_device
     int fix_bcap = 0, fix_k = 0;
     float* fix_q = nullptr;
@@ -373,7 +373,7 @@ static int ensure_ws(rq_index* idx, Workspace& w, int bpad, int64_t stride, int6
         if (int r = ensure(w.thr, 0, (size_t)bcap)) return r;
         if (int r = ensure(w.done, 0, (size_t)bcap)) return r;
         if (int r = ensure(w.ovf, 0, (size_t)bcap)) return r;
-        w.counters_dirty = true;
+        w.bincount_zero = w.done_zero = w.ovf_zero = false;
     }
     if (regrow_b || stride > w.pooled_stride) {
         const int64_t st = std::max(stride, w.pooled_stride);
@@ -465,18 +465,15 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     const float* scale = idx->inv_norm;
     if (metric == RQ_METRIC_IP) { if (int r = ensure_ones(idx, s)) return r; scale = idx->ones; }
 
-    const bool fused = fast && idx->fused_tail != 0;
-    if (fused) {
-        if (w.counters_dirty) {   // first use of this workspace, or the three-kernel tail ran on it
-            HIPCHK(hipMemsetAsync(w.bincount, 0, (size_t)w.bcap * sizeof(int), s));
-            HIPCHK(hipMemsetAsync(w.done, 0, (size_t)w.bcap * sizeof(int), s));
-            HIPCHK(hipMemsetAsync(w.ovf, 0, (size_t)w.bcap * sizeof(int), s));
-            w.counters_dirty = false;
-        }
-    }
+    const bool fused = fast && idx->fused_tail != 0;        // one tail kernel (0: collect / re-score / final as three kernels)
+    // counter protocol: the fused tail needs bincount/done/ovf zero on entry and leaves them zero; the three-kernel
+    // tail has its bincount zeroed by the query-preparation kernel and leaves it dirty.
+    if (fused && !w.done_zero) { HIPCHK(hipMemsetAsync(w.done, 0, (size_t)w.bcap * sizeof(int), s)); w.done_zero = true; }
+    if (fused && !w.bincount_zero) { HIPCHK(hipMemsetAsync(w.bincount, 0, (size_t)w.bcap * sizeof(int), s)); w.bincount_zero = true; }
+    if (fused && !w.ovf_zero) { HIPCHK(hipMemsetAsync(w.ovf, 0, (size_t)w.bcap * sizeof(int), s)); w.ovf_zero = true; }
     // unit-norm fp16 query fragments for the scan (+ padded fp32 queries / fp64 norms for the non-fused tails)
     HIPCHK(rq_prep_queries_launch(d_q, idx->dim, B, bpad, w.qh, w.q32, w.qn, fused ? nullptr : w.bincount, s));
-    if (!fused) w.counters_dirty = true;
+    if (!fused) w.bincount_zero = false;
     const int grid = (int)std::min<int64_t>(std::min<int64_t>(nquads, RQ_WGMAX_STRIDE), (int64_t)idx->cu_count * idx->wg_per_cu);
     if (!exact) {
         // non-temporal loads only for shards that cannot stay in the 256 MiB Infinity Cache between two scans
@@ -525,7 +522,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
                 ta.cand = w.cand; ta.bincount = w.bincount; ta.done = w.done; ta.ovf = w.ovf;
                 ta.out_scores = d_scores; ta.out_rows = d_rows; ta.out_keys = d_keys; ta.out_status = d_status;
                 ta.stop_after = idx->tail_stop;
-                if (idx->tail_stop) w.counters_dirty = true;   // a truncated tail does not reset its counters
+                if (idx->tail_stop) w.bincount_zero = w.done_zero = w.ovf_zero = false;   // a truncated tail does not reset its counters
                 const bool tprof = idx->profile == 2 && idx->ev_used < 16384;   // profile = 2: time the tail instead of the scan
                 if (tprof) {
                     if (idx->ev_used == idx->events.size()) {

@@ -368,47 +368,58 @@ hipError_t rq_merge_keys_launch(const uint64_t* keys, int n_per_query, int B, in
 //   reach T (one per workgroup counted), so every bin with pooled >= T is a candidate and every
 //   other bin is bounded by T -- which is all the certificate needs.
 // =============================================================================================
+template <int NV4>
 __global__ __launch_bounds__(256) void rq_collect_kernel(RqCollectArgs a) {
-    __shared__ __attribute__((aligned(16))) float vals[256];
     __shared__ float thr_s;
-    const int q = blockIdx.y, tid = threadIdx.x;
+    const int q = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float NEG_INF = -__builtin_huge_valf();
-    float v = NEG_INF;
-    const float* w = a.wgmax + (int64_t)q * a.wgmax_stride;
-    for (int i = tid; i < a.nwg; i += 256) v = fmaxf(v, w[i]);
-    vals[tid] = v;
-    if (tid == 0) thr_s = NEG_INF;
-    __syncthreads();
-    if (a.m <= 256) {
-        int rank = 0;
-#pragma unroll 4
-        for (int j = 0; j < 256; j += 4) {
-            const float4 o = *(const float4*)&vals[j];   // broadcast read
-            rank += ((o.x > v) || (o.x == v && j + 0 < tid)) ? 1 : 0;
-            rank += ((o.y > v) || (o.y == v && j + 1 < tid)) ? 1 : 0;
-            rank += ((o.z > v) || (o.z == v && j + 2 < tid)) ? 1 : 0;
-            rank += ((o.w > v) || (o.w == v && j + 3 < tid)) ? 1 : 0;
+    const float* p = a.pooled + (int64_t)q * a.pooled_stride;
+    const int64_t cbase = (int64_t)blockIdx.x * (1024 * NV4) + tid * 4;
+    float4 v4[NV4];
+#pragma unroll
+    for (int u = 0; u < NV4; ++u) {
+        const int64_t i = cbase + (int64_t)u * 1024;   // pooled_stride is a multiple of 64: in-bounds up to the stride
+        v4[u] = (i < a.pooled_stride) ? *(const float4*)(p + i) : make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
+    }
+    // threshold: ballot radix select (wave 0) of the m-th largest partition maximum, top 20 key bits
+    if (wave == 0) {
+        const float* w = a.wgmax + (int64_t)q * a.wgmax_stride;
+        uint32_t prefix = 0;
+        if (a.m <= 24) {
+            float v = NEG_INF;
+            for (int j = lane; j < a.nwg; j += 64) v = fmaxf(v, w[j]);
+            const uint32_t key = rq_mono32(v);
+            for (int bit = 31; bit >= 12; --bit) {
+                const uint32_t t = prefix | (1u << bit);
+                if (__popcll(__ballot(key >= t)) >= a.m) prefix = t;
+            }
+        } else if (a.m <= 256) {
+            uint32_t key[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = NEG_INF;
+                for (int j = i * 64 + lane; j < a.nwg; j += 256) v = fmaxf(v, w[j]);
+                key[i] = rq_mono32(v);
+            }
+            for (int bit = 31; bit >= 12; --bit) {
+                const uint32_t t = prefix | (1u << bit);
+                int c = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c += __popcll(__ballot(key[i] >= t));
+                if (c >= a.m) prefix = t;
+            }
         }
-        if (rank == a.m - 1) thr_s = v;   // exactly one thread has this rank
+        if (lane == 0) thr_s = prefix > rq_mono32(NEG_INF) ? rq_unmono32(prefix) : NEG_INF;
     }
     __syncthreads();
     const float T = thr_s;
     if (blockIdx.x == 0 && tid == 0) a.thr[q] = T;
-    // this workgroup's 4096 bins: 4 x float4 per thread, all loads issued before the first compare
-    const float* p = a.pooled + (int64_t)q * a.pooled_stride;
-    const int64_t base = (int64_t)blockIdx.x * 4096;
-    float4 v4[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int64_t i = base + (int64_t)u * 1024 + tid * 4;   // pooled_stride is a multiple of 64: in-bounds up to the stride
-        v4[u] = (i < a.pooled_stride) ? *(const float4*)(p + i) : make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NV4; ++u) {
         const float xs[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int64_t i = base + (int64_t)u * 1024 + tid * 4 + e;
+            const int64_t i = cbase + (int64_t)u * 1024 + e;
             if (i < a.nbins && xs[e] >= T) {
                 const int pos = atomicAdd(&a.bincount[q], 1);
                 if (pos < a.rmax) a.binlist[(int64_t)q * a.rmax + pos] = (int)i;
@@ -418,9 +429,16 @@ __global__ __launch_bounds__(256) void rq_collect_kernel(RqCollectArgs a) {
 }
 hipError_t rq_collect_launch(const RqCollectArgs& a, int B, hipStream_t stream) {
     if (a.m < 1 || a.rmax < 1 || a.rmax > RQ_FAST_MAX_BINS) return hipErrorInvalidValue;
-    const int64_t chunks = (a.nbins + 4095) / 4096;
-    if (chunks < 1 || chunks > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(rq_collect_kernel, dim3((unsigned)chunks, B), dim3(256), 0, stream, a);
+    const int64_t wgs1 = ((a.nbins + 1023) / 1024) * B;
+    if (wgs1 <= 1536) {
+        const int64_t chunks = (a.nbins + 1023) / 1024;
+        if (chunks < 1 || chunks > 65535) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(rq_collect_kernel<1>, dim3((unsigned)chunks, B), dim3(256), 0, stream, a);
+    } else {
+        const int64_t chunks = (a.nbins + 4095) / 4096;
+        if (chunks < 1 || chunks > 65535) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(rq_collect_kernel<4>, dim3((unsigned)chunks, B), dim3(256), 0, stream, a);
+    }
     return hipGetLastError();
 }
 
