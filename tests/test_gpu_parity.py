@@ -286,3 +286,58 @@ def test_full_size_properties(n):
     ms, mr = d.merge_keys_host(np.concatenate(parts, 1), 10)
     assert np.array_equal(mr, r10) and np.array_equal(ms, s10)
     idx.close()
+
+
+def test_nomic_bert_embedder_end_to_end_random_init():
+    """BASELINE.json configs[3] shape: raw text -> PyTorch-ROCm NomicBert forward -> HIP search.  No weights are
+    available offline, so the architecture runs with random weights (2 layers to keep the test quick) and a
+    byte-level stand-in tokenizer: this checks plumbing and exactness of the search over the produced embeddings,
+    not retrieval quality."""
+    import torch
+    from rag_uq_amd import streaming_index as si
+    from rag_uq_amd.embedders import NomicBertEmbedder
+    torch.manual_seed(0)
+    emb = NomicBertEmbedder(random_init=True, num_layers=2, device="cuda:0", dtype="float16", batch_size=256)
+    assert emb.dim == 768
+    texts = [f"passage {i}: the quick brown fox number {i * 7919 % 1000} jumps over topic {i % 13}" for i in range(600)]
+    vec = emb.embed(texts)
+    assert vec.shape == (600, 768) and np.isfinite(vec).all()
+    idx = si.DenseIndex(persist_directory="/tmp/rq_test_nomic", embedder=emb, load_persisted=False)
+    assert idx.add_documents([si.Document(id=f"p{i}", text=t) for i, t in enumerate(texts)], batch_size=256) == 600
+    queries = [texts[5], texts[123], "an unrelated question about rivers"] + [f"query text {i}" for i in range(253)]   # 256 raw text queries
+    res = idx.search_batch(queries, top_k=10)
+    assert len(res) == 256 and all(len(r) == 10 for r in res)
+    assert res[0][0][0] == "p5" and res[1][0][0] == "p123" and res[0][0][1] > 0.999
+    qv = emb.embed(queries)
+    x16 = orc.prepare_rows_f32(vec, True)
+    gs, gr = orc.dense_topk(qv, x16, 10)
+    got_rows = np.array([[int(d[1:]) for d, _, _ in r] for r in res])
+    got_scores = np.array([[s for _, s, _ in r] for r in res], dtype=np.float32)
+    assert np.array_equal(got_rows, gr) and float(np.abs(got_scores - gs).max()) <= SCORE_TOL
+    with pytest.raises(FileNotFoundError):
+        NomicBertEmbedder()          # no weights, no random_init: refuses, never downloads
+
+
+def test_three_million_rows_addressing_beyond_4gb():
+    """4.6 GB shard: every byte offset past 2^32 is exercised (scan, re-score, read-back).  Planted copies of
+    late rows must come back at rank 1 and one query is checked against the oracle outright."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 3_000_000
+    idx = nat.NativeIndex(768, 0)
+    idx.reserve(n)
+    for c in range(n // 250_000):
+        g = torch.Generator(device=dev); g.manual_seed(77 + c)
+        x = torch.nn.functional.normalize(torch.randn((250_000, 768), device=dev, generator=g), dim=1).half().contiguous()
+        idx.add_f16_device(x, 250_000)
+    del x
+    planted = [2_796_203, 2_999_999, 1_500_000, 2_147_483_648 // 1536 + 1]
+    q = np.concatenate([np.stack([idx.get_rows_f16(p, 1)[0] for p in planted]).astype(np.float32),
+                        orc.synthetic_queries(4, 768, seed=5)], 0)
+    s, r = idx.search(q, 10)
+    assert r[:4, 0].tolist() == planted and np.allclose(s[:4, 0], 1.0, atol=1e-6)
+    assert idx.timing()["exact_scans"] == 0
+    x16 = idx.get_rows_f16(0, n)
+    gs, gr = orc.dense_topk(q[3:5], x16, 10)
+    assert np.array_equal(r[3:5], gr) and float(np.abs(s[3:5] - gs).max()) <= SCORE_TOL
+    idx.close()

@@ -14,7 +14,7 @@ out = os.path.join(ROOT, "profiles")
 os.makedirs(out, exist_ok=True)
 
 def first(pattern):
-    g = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", pattern)))
+    g = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", pattern)), key=os.path.getmtime)
     return g[-1] if g else None
 
 ks = first("prof_bench/*/*kernel_stats.csv")
@@ -26,6 +26,23 @@ if ks:
         w.writeheader()
         w.writerows(keep)
     print("kernel stats:", [(r["Name"][:40], r["Calls"], round(float(r["AverageNs"]) / 1e3, 1)) for r in keep[:6]])
+
+ks1 = first("prof_bench_1s/*/*kernel_stats.csv")
+if ks1:
+    rows = list(csv.DictReader(open(ks1)))
+    with open(os.path.join(out, f"{tag}_bench_single_stream_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows([r for r in rows if "rq_" in r["Name"]])
+    print("single-stream kernel stats:", [(r["Name"][:40], r["Calls"], round(float(r["AverageNs"]) / 1e3, 1)) for r in rows if "rq_" in r["Name"]][:4])
+for logname in ("bench2", "prof_bench", "prof_bench_1s"):
+    lp = os.path.join(ROOT, "gpurun_out", logname + ".log")
+    if os.path.exists(lp):
+        lines = [l for l in open(lp, errors="replace").read().splitlines() if l.startswith('{"metric"')]
+        if lines:
+            open(os.path.join(out, f"{tag}_{logname}.json"), "w").write(lines[-1] + "\n")
+            d = json.loads(lines[-1])
+            print(logname, "value", round(d["value"]), "ms/step", round(d["ms_per_step"], 4), "scan avg us", round(d["roofline"]["avg_launch_us"], 1), "frac", round(d["roofline"]["frac"], 3))
 
 pmc = {}
 for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
