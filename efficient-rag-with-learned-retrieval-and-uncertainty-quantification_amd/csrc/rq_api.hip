@@ -92,7 +92,7 @@ struct rq_index {
     double* d_maxnorm = nullptr;   // device scalar, bits of the running max row norm
     double max_row_norm = 0.0;
     // options
-    int ring = 4, prefetch = 4, bin_tiles = 4, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, fast_tail = 1, pipeline = 0, fused_tail = 1, tail_stop = 0;
+    int ring = 4, prefetch = 4, kstage = 2, bin_tiles = 4, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, fast_tail = 1, pipeline = 0, fused_tail = 1, tail_stop = 0;
     double eps = -1.0;
     std::map<hipStream_t, StreamCtx> ctx;
     hipStream_t own_stream = nullptr;
@@ -315,7 +315,8 @@ extern "C" int rq_index_get_rows_f16(const rq_index* idx, int64_t row_begin, int
 extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     if (!idx || !name) return set_err(RQ_EINVAL, "bad option call");
     const std::string s(name);
-    if (s == "ring") { if (v < 3 || v > 6) return set_err(RQ_EINVAL, "ring must be 3..6"); idx->ring = (int)v; }
+    if (s == "ring") { if (v < 2 || v > 6) return set_err(RQ_EINVAL, "ring must be 2..6"); idx->ring = (int)v; }
+    else if (s == "kstage") { if (v != 1 && v != 2) return set_err(RQ_EINVAL, "kstage must be 1 or 2"); idx->kstage = (int)v; }
     else if (s == "prefetch") { if (v != 1 && v != 4 && v != 6 && v != 12) return set_err(RQ_EINVAL, "prefetch must be 1, 4, 6 or 12"); idx->prefetch = (int)v; }
     else if (s == "bin_tiles") { if (v != 1 && v != 2 && v != 4) return set_err(RQ_EINVAL, "bin_tiles must be 1, 2 or 4"); idx->bin_tiles = (int)v; }
     else if (s == "wg_per_cu") { if (v < 1 || v > 8) return set_err(RQ_EINVAL, "wg_per_cu must be 1..8"); idx->wg_per_cu = (int)v; }
@@ -335,6 +336,7 @@ extern "C" double rq_get_option(const rq_index* idx, const char* name) {
     const std::string s(name);
     if (s == "ring") return idx->ring;
     if (s == "prefetch") return idx->prefetch;
+    if (s == "kstage") return idx->kstage;
     if (s == "bin_tiles") return idx->bin_tiles;
     if (s == "wg_per_cu") return idx->wg_per_cu;
     if (s == "nt") return idx->nt;
@@ -501,7 +503,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
                 }
                 HIPCHK(hipEventRecord(idx->events[idx->ev_used].first, s));
             }
-            HIPCHK(rq_scan_launch(a, idx->ring, idx->prefetch, R, nt, grid, s));
+            HIPCHK(rq_scan_launch(a, idx->ring, idx->prefetch, idx->kstage, R, nt, grid, s));
             if (prof) { HIPCHK(hipEventRecord(idx->events[idx->ev_used].second, s)); idx->ev_used++; }
         }
         if (fast) {

@@ -17,8 +17,7 @@ struct RqScanArgs {
 };
 #define RQ_WGMAX_STRIDE 1024   // scan grids never exceed this many workgroups
 
-hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int R, bool nt, int grid, hipStream_t stream);
-size_t rq_scan_lds_bytes(int S);
+hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int ks, int R, bool nt, int grid, hipStream_t stream);
 
 // Row statistics at add time: row_norm64[i] = sqrt(sum x^2) in fp64, row_scale[i] = (float)(1/norm) or 0.
 hipError_t rq_rownorm_launch(const void* x, int64_t row_begin, int64_t row_end, double* norm64, hipStream_t stream);

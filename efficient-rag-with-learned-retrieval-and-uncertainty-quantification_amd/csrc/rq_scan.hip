@@ -20,8 +20,6 @@
 #include "rq_device.h"
 #include "rq_kernels.h"
 
-#define RQ_STAGE_BYTES 12288          // 16 rows x 768 B
-#define RQ_STAGE_CHUNKS 48            // 16-byte chunks per stage row
 #define RQ_NORM_BYTES 2048            // [2 parities][4 waves][64 floats]
 
 extern __shared__ __attribute__((aligned(16))) char rq_smem[];
@@ -35,13 +33,20 @@ __device__ __forceinline__ void rq_wait_vmcnt() {
 }
 
 // S: ring depth; R: tiles per bin; NT: non-temporal corpus loads; PF: A fragments read from LDS ahead of
-// their MFMAs (1, 4, 6 or 12); OCC: waves per SIMD the register allocation must allow.
-template <int S, int R, bool NT, int PF, int OCC>
+// their MFMAs (1, 4, 6 or 12); OCC: waves per SIMD the register allocation must allow; KS: stages per
+// tile (2: a stage is 16 half rows = 12 KiB; 1: a stage is 16 whole rows = 24 KiB contiguous in HBM).
+template <int S, int R, bool NT, int PF, int OCC, int KS>
 __global__ __launch_bounds__(256, OCC) void rq_scan_kernel(RqScanArgs a) {
-    static_assert(S >= 3 && S <= 8, "ring depth");
+    static_assert(S >= 2 && S <= 8, "ring depth");
     static_assert(PF == 1 || PF == 4 || PF == 6 || PF == 12, "fragment prefetch group");
     static_assert(R == 1 || R == 2 || R == 4, "tiles per bin");
-    constexpr int VM_KEEP = 3 * (S - 2);   // DMA ops of stages st+1 .. st+S-2 may stay in flight
+    static_assert(KS == 1 || KS == 2, "stages per tile");
+    constexpr int CH = 96 / KS;                    // 16-byte chunks per stage row
+    constexpr int STAGE_BYTES = 16 * CH * 16;      // 24576 / KS
+    constexpr int DPW = 6 / KS;                    // DMA wave-instructions per wave per stage
+    constexpr int MF = 24 / KS;                    // MFMAs per stage per wave
+    constexpr int NSTQ = 4 * KS;                   // stages per quad
+    constexpr int VM_KEEP = DPW * (S - 2);         // DMA ops of stages st+1 .. st+S-2 may stay in flight
     constexpr unsigned AUX = NT ? 2u : 0u;
 
     const int lane = threadIdx.x & 63;
@@ -51,12 +56,12 @@ __global__ __launch_bounds__(256, OCC) void rq_scan_kernel(RqScanArgs a) {
 
     // (query fragments are built after the DMA prologue has been issued, see below)
     // ---- per-lane DMA source offsets: LDS chunk p = 64*j + lane of a stage holds
-    //      row r = p / 48, source chunk c = (p % 48) ^ r   (r < 16, XOR stays inside a 16-chunk group)
-    unsigned voff[3];
+    //      row r = p / CH, source chunk c = (p % CH) ^ r   (r < 16, XOR stays inside a 16-chunk group)
+    unsigned voff[DPW];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int p = 64 * (wave * 3 + i) + lane;
-        const int r = p / RQ_STAGE_CHUNKS, cp = p % RQ_STAGE_CHUNKS;
+    for (int i = 0; i < DPW; ++i) {
+        const int p = 64 * (wave * DPW + i) + lane;
+        const int r = p / CH, cp = p % CH;
         voff[i] = (unsigned)(r * (RQ_DPAD * 2) + ((cp ^ r) << 4));
     }
     // ---- per-lane LDS read offsets: logical chunk 4*s + kg of row r16 sits at chunk ((4s+kg) ^ r16)
@@ -64,23 +69,23 @@ __global__ __launch_bounds__(256, OCC) void rq_scan_kernel(RqScanArgs a) {
     unsigned rbase[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
-        rbase[m] = (unsigned)(r16 * (RQ_STAGE_CHUNKS * 16) + ((kg ^ (r16 & 3)) << 4) + ((m ^ (r16 >> 2)) << 6));
+        rbase[m] = (unsigned)(r16 * (CH * 16) + ((kg ^ (r16 & 3)) << 4) + ((m ^ (r16 >> 2)) << 6));
 
     const int G = gridDim.x, b = blockIdx.x;
     const int nloc = (a.nquads > b) ? (a.nquads - b + G - 1) / G : 0;
-    const int nst = nloc * 8;
+    const int nst = nloc * NSTQ;
     const char* xb = (const char*)a.x;
-    char* norm_lds = rq_smem + S * RQ_STAGE_BYTES;
+    char* norm_lds = rq_smem + S * STAGE_BYTES;
 
     auto issue = [&](int st, int slot) {
-        const int lq = st >> 3, t = (st >> 1) & 3, kh = st & 1;
+        const int lq = st / NSTQ, t = (st / KS) & 3, kh = st % KS;
         const int64_t quad = (int64_t)b + (int64_t)lq * G;
-        const char* g = xb + (quad * RQ_QUAD_ROWS + t * RQ_TILE_ROWS) * (int64_t)(RQ_DPAD * 2) + kh * RQ_DPAD;
-        char* l = rq_smem + slot * RQ_STAGE_BYTES + (wave * 3) * 1024;
+        const char* g = xb + (quad * RQ_QUAD_ROWS + t * RQ_TILE_ROWS) * (int64_t)(RQ_DPAD * 2) + kh * (RQ_DPAD * 2 / KS);
+        char* l = rq_smem + slot * STAGE_BYTES + (wave * DPW) * 1024;
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < DPW; ++i)
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(g + voff[i]), (lds_ptr_t)(l + i * 1024), 16, 0, AUX);
-        if ((st & 7) == 0) {   // row scales of the quad, one private copy per wave (256 B)
+        if ((st % NSTQ) == 0) {   // row scales of the quad, one private copy per wave (256 B)
             const float* ns = a.row_scale + quad * RQ_QUAD_ROWS + lane;
             __builtin_amdgcn_global_load_lds((glb_ptr_t)ns, (lds_ptr_t)(norm_lds + (((lq & 1) * 4 + wave) << 8)), 4, 0, 0);
         }
@@ -117,21 +122,21 @@ __global__ __launch_bounds__(256, OCC) void rq_scan_kernel(RqScanArgs a) {
         for (int t = 0; t < 4; ++t) {
             rq_float4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kh = 0; kh < 2; ++kh) {
-                const int st = lq * 8 + t * 2 + kh;
+            for (int kh = 0; kh < KS; ++kh) {
+                const int st = lq * NSTQ + t * KS + kh;
                 if (st + S - 2 <= nst - 1) rq_wait_vmcnt<VM_KEEP>(); else rq_wait_vmcnt<0>();
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 if (st + S - 1 < nst) { issue(st + S - 1, islot); islot = (islot + 1 == S) ? 0 : islot + 1; }
-                const char* sb = rq_smem + cslot * RQ_STAGE_BYTES;
+                const char* sb = rq_smem + cslot * STAGE_BYTES;
                 cslot = (cslot + 1 == S) ? 0 : cslot + 1;
 #pragma unroll
-                for (int g = 0; g < 12; g += PF) {
+                for (int g = 0; g < MF; g += PF) {
                     rq_half8 av[PF];
 #pragma unroll
                     for (int s = 0; s < PF; ++s) av[s] = *(const rq_half8*)(sb + rbase[(g + s) & 3] + (((g + s) & ~3) << 6));
 #pragma unroll
-                    for (int s = 0; s < PF; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[s], qf[kh * 12 + g + s], acc, 0, 0, 0);
+                    for (int s = 0; s < PF; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[s], qf[kh * MF + g + s], acc, 0, 0, 0);
                 }
             }
             // tile epilogue: D[row = 4*kg + i][query = r16]
@@ -165,42 +170,40 @@ __global__ __launch_bounds__(256, OCC) void rq_scan_kernel(RqScanArgs a) {
     if (kg == 0 && 16 * wave + r16 < a.nq_valid) a.wgmax[(int64_t)(16 * wave + r16) * a.wgmax_stride + b] = wmax;
 }
 
-template <int S, int R, bool NT, int PF, int OCC>
+template <int S, int R, bool NT, int PF, int OCC, int KS>
 static hipError_t rq_scan_launch_t(const RqScanArgs& a, int grid, hipStream_t stream) {
-    const size_t lds = (size_t)S * RQ_STAGE_BYTES + RQ_NORM_BYTES;
+    const size_t lds = (size_t)S * (24576 / KS) + RQ_NORM_BYTES;
     static unsigned long long attr_done = 0;   // one bit per device
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (!((attr_done >> (dev & 63)) & 1ull)) {
-        e = hipFuncSetAttribute((const void*)rq_scan_kernel<S, R, NT, PF, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipFuncSetAttribute((const void*)rq_scan_kernel<S, R, NT, PF, OCC, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done |= 1ull << (dev & 63);
     }
-    hipLaunchKernelGGL((rq_scan_kernel<S, R, NT, PF, OCC>), dim3(grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((rq_scan_kernel<S, R, NT, PF, OCC, KS>), dim3(grid), dim3(256), lds, stream, a);
     return hipGetLastError();
 }
 
-template <int S, int PF, int OCC>
+template <int S, int PF, int OCC, int KS>
 static hipError_t rq_scan_launch_r(const RqScanArgs& a, int R, bool nt, int grid, hipStream_t stream) {
     switch (R) {
-        case 4: return nt ? rq_scan_launch_t<S, 4, true, PF, OCC>(a, grid, stream) : rq_scan_launch_t<S, 4, false, PF, OCC>(a, grid, stream);
-        case 2: return nt ? rq_scan_launch_t<S, 2, true, PF, OCC>(a, grid, stream) : rq_scan_launch_t<S, 2, false, PF, OCC>(a, grid, stream);
-        case 1: return nt ? rq_scan_launch_t<S, 1, true, PF, OCC>(a, grid, stream) : rq_scan_launch_t<S, 1, false, PF, OCC>(a, grid, stream);
+        case 4: return nt ? rq_scan_launch_t<S, 4, true, PF, OCC, KS>(a, grid, stream) : rq_scan_launch_t<S, 4, false, PF, OCC, KS>(a, grid, stream);
+        case 2: return nt ? rq_scan_launch_t<S, 2, true, PF, OCC, KS>(a, grid, stream) : rq_scan_launch_t<S, 2, false, PF, OCC, KS>(a, grid, stream);
+        case 1: return nt ? rq_scan_launch_t<S, 1, true, PF, OCC, KS>(a, grid, stream) : rq_scan_launch_t<S, 1, false, PF, OCC, KS>(a, grid, stream);
         default: return hipErrorInvalidValue;
     }
 }
 
-size_t rq_scan_lds_bytes(int S) { return (size_t)S * RQ_STAGE_BYTES + RQ_NORM_BYTES; }
-
-// variant = 10 * S + code:  code 0: PF 1, 3 waves/SIMD;  1: PF 4, 2 waves/SIMD;  2: PF 12, 2 waves/SIMD; 3: PF 6, 2 waves/SIMD
-hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int R, bool nt, int grid, hipStream_t stream) {
+// (ring S, prefetch PF, stages-per-tile KS) combinations that are built; anything else is an error.
+hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int ks, int R, bool nt, int grid, hipStream_t stream) {
     if (grid <= 0) return hipErrorInvalidValue;
-#define RQ_CASE(SS, PP, OO) if (S == SS && pf == PP) return rq_scan_launch_r<SS, PP, OO>(a, R, nt, grid, stream);
-    RQ_CASE(3, 1, 3) RQ_CASE(4, 1, 3)
-    RQ_CASE(4, 4, 2) RQ_CASE(5, 4, 2) RQ_CASE(6, 4, 2)
-    RQ_CASE(4, 6, 2) RQ_CASE(5, 6, 2) RQ_CASE(6, 6, 2)
-    RQ_CASE(4, 12, 2) RQ_CASE(5, 12, 2) RQ_CASE(6, 12, 2)
+#define RQ_CASE(SS, PP, OO, KK) if (S == SS && pf == PP && ks == KK) return rq_scan_launch_r<SS, PP, OO, KK>(a, R, nt, grid, stream);
+    RQ_CASE(3, 1, 3, 2) RQ_CASE(4, 1, 3, 2)
+    RQ_CASE(4, 4, 2, 2) RQ_CASE(6, 4, 2, 2)
+    RQ_CASE(5, 6, 2, 2) RQ_CASE(6, 12, 2, 2)
+    RQ_CASE(2, 4, 2, 1) RQ_CASE(3, 4, 2, 1) RQ_CASE(3, 12, 2, 1) RQ_CASE(2, 1, 3, 1) RQ_CASE(4, 4, 2, 1)
 #undef RQ_CASE
     return hipErrorInvalidValue;
 }

@@ -341,3 +341,46 @@ def test_three_million_rows_addressing_beyond_4gb():
     gs, gr = orc.dense_topk(q[3:5], x16, 10)
     assert np.array_equal(r[3:5], gr) and float(np.abs(s[3:5] - gs).max()) <= SCORE_TOL
     idx.close()
+
+
+def test_randomised_shapes_sweep():
+    """40 seeded random cases: ragged N / dim / B / k, both metrics, injected duplicate runs, zero rows,
+    zero queries and planted queries -- every one must match the oracle exactly."""
+    rng = np.random.default_rng(20261004)
+    for case in range(40):
+        n = int(rng.choice([1, 2, 17, 63, 64, 65, 200, 1023, 1025, 3000, 7777]))
+        dim = int(rng.choice([1, 3, 32, 100, 384, 767, 768]))
+        B = int(rng.choice([1, 2, 15, 16, 17, 64, 65, 129]))
+        k = int(rng.choice([1, 2, 10, 33, 128, 129, 300]))
+        metric = int(rng.integers(0, 2))
+        x = rng.standard_normal((n, dim)).astype(np.float32) * float(rng.choice([0.01, 1.0, 20.0]))
+        if n > 20 and rng.random() < 0.5:
+            lo = int(rng.integers(0, n - 10)); x[lo:lo + int(rng.integers(2, min(n - lo, 200)))] = x[lo]
+        if n > 5 and rng.random() < 0.5:
+            x[int(rng.integers(0, n))] = 0
+        x16 = x.astype(np.float16) if metric == 1 else orc.prepare_rows_f32(x, True)
+        q = rng.standard_normal((B, dim)).astype(np.float32) * float(rng.choice([1e-3, 1.0, 50.0]))
+        if rng.random() < 0.3:
+            q[int(rng.integers(0, B))] = 0
+        if rng.random() < 0.5:
+            q[int(rng.integers(0, B))] = x16[int(rng.integers(0, n))].astype(np.float32)
+        idx = nat.NativeIndex(dim, 0)
+        idx.add_f16(x16)
+        try:
+            _check(idx, x16, q, k, metric)
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: n={n} dim={dim} B={B} k={k} metric={metric}: {e}")
+        idx.close()
+
+
+def test_option_validation_and_status_codes():
+    idx = nat.NativeIndex(8, 0)
+    for name, bad in [("ring", 9), ("bin_tiles", 3), ("wg_per_cu", 0), ("prefetch", 5), ("kstage", 3), ("nonsense", 1)]:
+        with pytest.raises(nat.RqError):
+            idx.set_option(name, bad)
+    idx.set_option("ring", 6); assert idx.get_option("ring") == 6
+    assert idx.get_option("eps") == pytest.approx(7e-4)
+    assert idx.get_option("cu_count") == 256
+    with pytest.raises(nat.RqError):
+        idx.get_rows_f16(0, 1)              # outside the (empty) index
+    idx.close()
