@@ -92,7 +92,7 @@ struct rq_index {
     double* d_maxnorm = nullptr;   // device scalar, bits of the running max row norm
     double max_row_norm = 0.0;
     // options
-    int ring = 4, prefetch = 4, kstage = 2, bin_tiles = 4, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, fast_tail = 1, pipeline = 0, fused_tail = 1, tail_stop = 0;
+    int ring = 4, prefetch = 4, kstage = 2, wide_batch = 1, bin_tiles = 4, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, fast_tail = 1, pipeline = 0, fused_tail = 1, tail_stop = 0;
     double eps = -1.0;
     std::map<hipStream_t, StreamCtx> ctx;
     hipStream_t own_stream = nullptr;
@@ -316,6 +316,7 @@ extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     if (!idx || !name) return set_err(RQ_EINVAL, "bad option call");
     const std::string s(name);
     if (s == "ring") { if (v < 2 || v > 6) return set_err(RQ_EINVAL, "ring must be 2..6"); idx->ring = (int)v; }
+    else if (s == "wide_batch") idx->wide_batch = (int)v;
     else if (s == "kstage") { if (v != 1 && v != 2) return set_err(RQ_EINVAL, "kstage must be 1 or 2"); idx->kstage = (int)v; }
     else if (s == "prefetch") { if (v != 1 && v != 4 && v != 6 && v != 12) return set_err(RQ_EINVAL, "prefetch must be 1, 4, 6 or 12"); idx->prefetch = (int)v; }
     else if (s == "bin_tiles") { if (v != 1 && v != 2 && v != 4) return set_err(RQ_EINVAL, "bin_tiles must be 1, 2 or 4"); idx->bin_tiles = (int)v; }
@@ -337,6 +338,7 @@ extern "C" double rq_get_option(const rq_index* idx, const char* name) {
     if (s == "ring") return idx->ring;
     if (s == "prefetch") return idx->prefetch;
     if (s == "kstage") return idx->kstage;
+    if (s == "wide_batch") return idx->wide_batch;
     if (s == "bin_tiles") return idx->bin_tiles;
     if (s == "wg_per_cu") return idx->wg_per_cu;
     if (s == "nt") return idx->nt;
@@ -437,7 +439,9 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     const bool exact = nb < 0 || nb >= nbins;
     if (exact) nb = (int)std::min<int64_t>(nbins, INT32_MAX / 64);
     if (!exact && nb > RQ_NB_MAX) return set_err(RQ_EINVAL, "nb %d too large", nb);
-    const int bpad = (B + 63) / 64 * 64;
+    // queries per corpus pass: 128 (8 waves per workgroup, one workgroup per CU) once a call has more than 64
+    const int qb = (idx->wide_batch && B > 64) ? 128 : 64;
+    const int bpad = (B + qb - 1) / qb * qb;
     const int64_t stride = (nbins + 63) / 64 * 64;
     const int m = nb + 1;
     const bool fast = !exact && idx->fast_tail && m <= RQ_FAST_MAX_M && k <= RQ_FAST_MAX_K;
@@ -476,22 +480,23 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     // unit-norm fp16 query fragments for the scan (+ padded fp32 queries / fp64 norms for the non-fused tails)
     HIPCHK(rq_prep_queries_launch(d_q, idx->dim, B, bpad, w.qh, w.q32, w.qn, fused ? nullptr : w.bincount, s));
     if (!fused) w.bincount_zero = false;
-    const int grid = (int)std::min<int64_t>(std::min<int64_t>(nquads, RQ_WGMAX_STRIDE), (int64_t)idx->cu_count * idx->wg_per_cu);
+    const int grid = (int)std::min<int64_t>(std::min<int64_t>(nquads, RQ_WGMAX_STRIDE),
+                                            (int64_t)idx->cu_count * (qb == 128 ? 1 : idx->wg_per_cu));
     if (!exact) {
         // non-temporal loads only for shards that cannot stay in the 256 MiB Infinity Cache between two scans
         // (measured: 192 MB shard 36 us with default policy vs 39 us nt; 1.5 GB shard 250 us nt vs 285 us default)
         const bool nt = idx->nt < 0 ? (idx->n * (int64_t)(RQ_DPAD * 2) > ((int64_t)208 << 20)) : idx->nt != 0;
-        for (int blk = 0; blk < bpad / 64; ++blk) {
+        for (int blk = 0; blk < bpad / qb; ++blk) {
             RqScanArgs a;
             a.x = idx->x;
             a.row_scale = scale;
-            a.qh = w.qh + (size_t)blk * 64 * RQ_DPAD;
-            a.pooled = w.pooled + (size_t)blk * 64 * w.pooled_stride;
+            a.qh = w.qh + (size_t)blk * qb * RQ_DPAD;
+            a.pooled = w.pooled + (size_t)blk * qb * w.pooled_stride;
             a.pooled_stride = w.pooled_stride;
             a.n_rows = idx->n;
             a.nquads = nquads;
-            a.nq_valid = std::min(64, B - blk * 64);
-            a.wgmax = w.wgmax + (size_t)blk * 64 * RQ_WGMAX_STRIDE;
+            a.nq_valid = std::min(qb, B - blk * qb);
+            a.wgmax = w.wgmax + (size_t)blk * qb * RQ_WGMAX_STRIDE;
             a.wgmax_stride = RQ_WGMAX_STRIDE;
             const bool prof = idx->profile == 1 && idx->ev_used < 16384;
             if (prof) {
@@ -503,7 +508,8 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
                 }
                 HIPCHK(hipEventRecord(idx->events[idx->ev_used].first, s));
             }
-            HIPCHK(rq_scan_launch(a, idx->ring, idx->prefetch, idx->kstage, R, nt, grid, s));
+            if (qb == 128) HIPCHK(rq_scan_launch(a, 3, 4, 1, 8, R, nt, grid, s));
+            else HIPCHK(rq_scan_launch(a, idx->ring, idx->prefetch, idx->kstage, 4, R, nt, grid, s));
             if (prof) { HIPCHK(hipEventRecord(idx->events[idx->ev_used].second, s)); idx->ev_used++; }
         }
         if (fast) {

@@ -6,18 +6,18 @@
 struct RqScanArgs {
     const void* x;            // fp16 corpus shard [rows_padded][768], rows_padded % 64 == 0, pad rows zero
     const float* row_scale;   // [rows_padded] 1/||row|| (cosine) or 1.0 (inner product); pad entries 0
-    const _Float16* qh;       // [64][768] unit-norm fp16 queries of this block, unused slots zero
-    float* pooled;            // [64][pooled_stride] per-bin maxima of the approximate score
+    const _Float16* qh;       // [QB][768] unit-norm fp16 queries of this block (QB = 64 or 128), unused slots zero
+    float* pooled;            // [QB][pooled_stride] per-bin maxima of the approximate score
     int64_t pooled_stride;    // floats per query row, >= nquads * 16 / R
     int64_t n_rows;           // valid rows of the shard
     int nquads;               // ceil(n_rows / 64)
-    int nq_valid;             // queries of this block that are real (<= 64)
-    float* wgmax;             // [64][wgmax_stride] best pooled value per (query, scan workgroup)
+    int nq_valid;             // queries of this block that are real (<= QB)
+    float* wgmax;             // [QB][wgmax_stride] best pooled value per (query, scan workgroup)
     int wgmax_stride;         // >= grid
 };
 #define RQ_WGMAX_STRIDE 1024   // scan grids never exceed this many workgroups
 
-hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int ks, int R, bool nt, int grid, hipStream_t stream);
+hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int ks, int qw, int R, bool nt, int grid, hipStream_t stream);
 
 // Row statistics at add time: row_norm64[i] = sqrt(sum x^2) in fp64, row_scale[i] = (float)(1/norm) or 0.
 hipError_t rq_rownorm_launch(const void* x, int64_t row_begin, int64_t row_end, double* norm64, hipStream_t stream);

@@ -20,7 +20,6 @@
 #include "rq_device.h"
 #include "rq_kernels.h"
 
-#define RQ_NORM_BYTES 2048            // [2 parities][4 waves][64 floats]
 
 extern __shared__ __attribute__((aligned(16))) char rq_smem[];
 
@@ -34,16 +33,18 @@ __device__ __forceinline__ void rq_wait_vmcnt() {
 
 // S: ring depth; R: tiles per bin; NT: non-temporal corpus loads; PF: A fragments read from LDS ahead of
 // their MFMAs (1, 4, 6 or 12); OCC: waves per SIMD the register allocation must allow; KS: stages per
-// tile (2: a stage is 16 half rows = 12 KiB; 1: a stage is 16 whole rows = 24 KiB contiguous in HBM).
-template <int S, int R, bool NT, int PF, int OCC, int KS>
-__global__ __launch_bounds__(256, OCC) void rq_scan_kernel(RqScanArgs a) {
+// tile (2: a stage is 16 half rows = 12 KiB; 1: a stage is 16 whole rows = 24 KiB contiguous in HBM);
+// QW: waves per workgroup = 16-query groups scored per corpus pass (4: 64 queries, 8: 128 queries).
+template <int S, int R, bool NT, int PF, int OCC, int KS, int QW>
+__global__ __launch_bounds__(64 * QW, OCC) void rq_scan_kernel(RqScanArgs a) {
     static_assert(S >= 2 && S <= 8, "ring depth");
     static_assert(PF == 1 || PF == 4 || PF == 6 || PF == 12, "fragment prefetch group");
     static_assert(R == 1 || R == 2 || R == 4, "tiles per bin");
     static_assert(KS == 1 || KS == 2, "stages per tile");
     constexpr int CH = 96 / KS;                    // 16-byte chunks per stage row
     constexpr int STAGE_BYTES = 16 * CH * 16;      // 24576 / KS
-    constexpr int DPW = 6 / KS;                    // DMA wave-instructions per wave per stage
+    static_assert((24 / KS) % QW == 0, "DMA instructions of a stage must split evenly over the waves");
+    constexpr int DPW = 24 / KS / QW;              // DMA wave-instructions per wave per stage
     constexpr int MF = 24 / KS;                    // MFMAs per stage per wave
     constexpr int NSTQ = 4 * KS;                   // stages per quad
     constexpr int VM_KEEP = DPW * (S - 2);         // DMA ops of stages st+1 .. st+S-2 may stay in flight
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256, OCC) void rq_scan_kernel(RqScanArgs a) {
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(g + voff[i]), (lds_ptr_t)(l + i * 1024), 16, 0, AUX);
         if ((st % NSTQ) == 0) {   // row scales of the quad, one private copy per wave (256 B)
             const float* ns = a.row_scale + quad * RQ_QUAD_ROWS + lane;
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)ns, (lds_ptr_t)(norm_lds + (((lq & 1) * 4 + wave) << 8)), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)ns, (lds_ptr_t)(norm_lds + (((lq & 1) * QW + wave) << 8)), 4, 0, 0);
         }
     };
 
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256, OCC) void rq_scan_kernel(RqScanArgs a) {
         float binmax[4 / R];
 #pragma unroll
         for (int u = 0; u < 4 / R; ++u) binmax[u] = NEG_INF;
-        const char* nrow = norm_lds + (((lq & 1) * 4 + wave) << 8) + kg * 16;
+        const char* nrow = norm_lds + (((lq & 1) * QW + wave) << 8) + kg * 16;
 
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -170,40 +171,42 @@ __global__ __launch_bounds__(256, OCC) void rq_scan_kernel(RqScanArgs a) {
     if (kg == 0 && 16 * wave + r16 < a.nq_valid) a.wgmax[(int64_t)(16 * wave + r16) * a.wgmax_stride + b] = wmax;
 }
 
-template <int S, int R, bool NT, int PF, int OCC, int KS>
+template <int S, int R, bool NT, int PF, int OCC, int KS, int QW>
 static hipError_t rq_scan_launch_t(const RqScanArgs& a, int grid, hipStream_t stream) {
-    const size_t lds = (size_t)S * (24576 / KS) + RQ_NORM_BYTES;
+    const size_t lds = (size_t)S * (24576 / KS) + 2 * QW * 256;   // ring + [2 parities][QW waves][64 row scales]
     static unsigned long long attr_done = 0;   // one bit per device
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (!((attr_done >> (dev & 63)) & 1ull)) {
-        e = hipFuncSetAttribute((const void*)rq_scan_kernel<S, R, NT, PF, OCC, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipFuncSetAttribute((const void*)rq_scan_kernel<S, R, NT, PF, OCC, KS, QW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done |= 1ull << (dev & 63);
     }
-    hipLaunchKernelGGL((rq_scan_kernel<S, R, NT, PF, OCC, KS>), dim3(grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((rq_scan_kernel<S, R, NT, PF, OCC, KS, QW>), dim3(grid), dim3(64 * QW), lds, stream, a);
     return hipGetLastError();
 }
 
-template <int S, int PF, int OCC, int KS>
+template <int S, int PF, int OCC, int KS, int QW>
 static hipError_t rq_scan_launch_r(const RqScanArgs& a, int R, bool nt, int grid, hipStream_t stream) {
     switch (R) {
-        case 4: return nt ? rq_scan_launch_t<S, 4, true, PF, OCC, KS>(a, grid, stream) : rq_scan_launch_t<S, 4, false, PF, OCC, KS>(a, grid, stream);
-        case 2: return nt ? rq_scan_launch_t<S, 2, true, PF, OCC, KS>(a, grid, stream) : rq_scan_launch_t<S, 2, false, PF, OCC, KS>(a, grid, stream);
-        case 1: return nt ? rq_scan_launch_t<S, 1, true, PF, OCC, KS>(a, grid, stream) : rq_scan_launch_t<S, 1, false, PF, OCC, KS>(a, grid, stream);
+        case 4: return nt ? rq_scan_launch_t<S, 4, true, PF, OCC, KS, QW>(a, grid, stream) : rq_scan_launch_t<S, 4, false, PF, OCC, KS, QW>(a, grid, stream);
+        case 2: return nt ? rq_scan_launch_t<S, 2, true, PF, OCC, KS, QW>(a, grid, stream) : rq_scan_launch_t<S, 2, false, PF, OCC, KS, QW>(a, grid, stream);
+        case 1: return nt ? rq_scan_launch_t<S, 1, true, PF, OCC, KS, QW>(a, grid, stream) : rq_scan_launch_t<S, 1, false, PF, OCC, KS, QW>(a, grid, stream);
         default: return hipErrorInvalidValue;
     }
 }
 
-// (ring S, prefetch PF, stages-per-tile KS) combinations that are built; anything else is an error.
-hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int ks, int R, bool nt, int grid, hipStream_t stream) {
+// (ring S, prefetch PF, stages-per-tile KS, waves QW) combinations that are built; anything else is an error.
+// qw = 4: 64 queries per pass; qw = 8: 128 queries per pass (one workgroup per CU, whole-row stages).
+hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int ks, int qw, int R, bool nt, int grid, hipStream_t stream) {
     if (grid <= 0) return hipErrorInvalidValue;
-#define RQ_CASE(SS, PP, OO, KK) if (S == SS && pf == PP && ks == KK) return rq_scan_launch_r<SS, PP, OO, KK>(a, R, nt, grid, stream);
-    RQ_CASE(3, 1, 3, 2) RQ_CASE(4, 1, 3, 2)
-    RQ_CASE(4, 4, 2, 2) RQ_CASE(6, 4, 2, 2)
-    RQ_CASE(5, 6, 2, 2) RQ_CASE(6, 12, 2, 2)
-    RQ_CASE(2, 4, 2, 1) RQ_CASE(3, 4, 2, 1) RQ_CASE(3, 12, 2, 1) RQ_CASE(2, 1, 3, 1) RQ_CASE(4, 4, 2, 1)
+#define RQ_CASE(SS, PP, OO, KK, QQ) if (S == SS && pf == PP && ks == KK && qw == QQ) return rq_scan_launch_r<SS, PP, OO, KK, QQ>(a, R, nt, grid, stream);
+    RQ_CASE(3, 1, 3, 2, 4) RQ_CASE(4, 1, 3, 2, 4)
+    RQ_CASE(4, 4, 2, 2, 4) RQ_CASE(6, 4, 2, 2, 4)
+    RQ_CASE(5, 6, 2, 2, 4) RQ_CASE(6, 12, 2, 2, 4)
+    RQ_CASE(2, 4, 2, 1, 4) RQ_CASE(3, 4, 2, 1, 4) RQ_CASE(3, 12, 2, 1, 4) RQ_CASE(2, 1, 3, 1, 4) RQ_CASE(4, 4, 2, 1, 4)
+    RQ_CASE(3, 4, 2, 1, 8) RQ_CASE(4, 4, 2, 1, 8) RQ_CASE(2, 4, 2, 1, 8)
 #undef RQ_CASE
     return hipErrorInvalidValue;
 }
