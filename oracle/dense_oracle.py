@@ -119,22 +119,61 @@ def merge_topk(parts: Sequence[Tuple[np.ndarray, np.ndarray]], k: int) -> Tuple[
 # near-ties, which is why it is the *timed baseline* and not the parity oracle).
 # ---------------------------------------------------------------------------------------------
 class Fp32BruteForce:
-    def __init__(self, x16: np.ndarray):
-        self.x32 = np.ascontiguousarray(x16.astype(np.float32))
-        self.inv = 1.0 / np.maximum(np.sqrt((self.x32.astype(np.float64) ** 2).sum(axis=1)), 1e-30)
-        self.inv = self.inv.astype(np.float32)
+    """Row-blocked, multi-threaded brute force: every worker thread owns a slice of corpus rows, runs a
+    single-threaded OpenBLAS GEMM on it and keeps the slice's top-k; the slices are merged at the end.
+    (numpy releases the GIL inside matmul / argpartition, so the threads really run in parallel.)"""
 
-    def search(self, q: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray]:
+    def __init__(self, x16: np.ndarray, n_threads: int = 0, block_rows: int = 16384):
+        import os
+        self.x32 = np.ascontiguousarray(x16.astype(np.float32))
+        self.inv = (1.0 / np.maximum(np.sqrt((self.x32.astype(np.float64) ** 2).sum(axis=1)), 1e-30)).astype(np.float32)
+        self.n_threads = n_threads or len(os.sched_getaffinity(0))
+        self.block_rows = block_rows
+
+    def _block(self, q: np.ndarray, qn: np.ndarray, lo: int, hi: int, k: int):
+        s = (q @ self.x32[lo:hi].T) * self.inv[None, lo:hi] / (qn[:, None] + 1e-30)
+        ke = min(k, hi - lo)
+        part = np.argpartition(-s, ke - 1, axis=1)[:, :ke]
+        return np.take_along_axis(s, part, axis=1), part.astype(np.int64) + lo
+
+    def search_blas(self, q: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray]:
+        """One multi-threaded OpenBLAS GEMM over the whole corpus, then numpy's (single-threaded) argpartition."""
         q = np.atleast_2d(np.asarray(q, dtype=np.float32))
         qn = np.sqrt((q.astype(np.float64) ** 2).sum(axis=1)).astype(np.float32)
-        s = (q @ self.x32.T) * self.inv[None, :] / (qn[:, None] + 1e-30)
-        N = s.shape[1]
-        ke = min(k, N)
-        part = np.sort(np.argpartition(-s, ke - 1, axis=1)[:, :ke], axis=1)   # rows ascending: stable sort breaks ties by row
-        ps = np.take_along_axis(s, part, axis=1)
-        order = np.argsort(-ps, axis=1, kind="stable")
-        rows = np.take_along_axis(part, order, axis=1)
-        return np.take_along_axis(ps, order, axis=1), rows.astype(np.int64)
+        s, r = self._block(q, qn, 0, self.x32.shape[0], k)
+        o = np.argsort(r, axis=1, kind="stable")
+        s, r = np.take_along_axis(s, o, axis=1), np.take_along_axis(r, o, axis=1)
+        o = np.argsort(-s, axis=1, kind="stable")
+        return np.take_along_axis(s, o, axis=1), np.take_along_axis(r, o, axis=1)
+
+    def search(self, q: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray]:
+        from concurrent.futures import ThreadPoolExecutor
+        q = np.atleast_2d(np.asarray(q, dtype=np.float32))
+        qn = np.sqrt((q.astype(np.float64) ** 2).sum(axis=1)).astype(np.float32)
+        n = self.x32.shape[0]
+        spans = [(lo, min(lo + self.block_rows, n)) for lo in range(0, n, self.block_rows)]
+        try:
+            from threadpoolctl import threadpool_limits
+            limit = threadpool_limits(limits=1)      # one BLAS thread per worker: the pool provides the parallelism
+        except Exception:                            # pragma: no cover
+            limit = None
+        try:
+            if self.n_threads > 1 and len(spans) > 1:
+                with ThreadPoolExecutor(max_workers=self.n_threads) as ex:
+                    parts = list(ex.map(lambda sp: self._block(q, qn, sp[0], sp[1], k), spans))
+            else:
+                parts = [self._block(q, qn, lo, hi, k) for lo, hi in spans]
+        finally:
+            if limit is not None:
+                limit.restore_original_limits()
+        s = np.concatenate([p[0] for p in parts], axis=1)
+        r = np.concatenate([p[1] for p in parts], axis=1)
+        ke = min(k, n)
+        # rows ascending first, then a stable sort by score: ties end up ordered by row
+        o = np.argsort(r, axis=1, kind="stable")
+        s, r = np.take_along_axis(s, o, axis=1), np.take_along_axis(r, o, axis=1)
+        o = np.argsort(-s, axis=1, kind="stable")[:, :ke]
+        return np.take_along_axis(s, o, axis=1), np.take_along_axis(r, o, axis=1)
 
 
 def recall_at_k(found_rows: np.ndarray, gold_rows: np.ndarray) -> float:
