@@ -233,7 +233,8 @@ class DenseIndex:
 
     def __init__(self, collection_name: str = "rag_documents", persist_directory: str = "./data/chroma_db",
                  embedding_model: str = "nomic-embed-text", chroma_host: Optional[str] = None, chroma_port: int = 8000,
-                 *, embedder=None, device: int = 0, metric: str = "cosine", load_persisted: bool = True):
+                 *, embedder=None, device: int = 0, devices: Optional[Sequence[int]] = None, metric: str = "cosine",
+                 load_persisted: bool = True):
         self.collection_name = collection_name
         self.persist_directory = persist_directory
         self.embedding_model = embedding_model
@@ -243,6 +244,7 @@ class DenseIndex:
             raise ImportError("a gfx950 GPU (librq_hip.so backend) is required for DenseIndex")
         self.embedder = embedder if embedder is not None else default_embedder(embedding_model)
         self.device = int(device)
+        self.devices = [int(d) for d in devices] if devices else None     # several GPUs in this process: rows are sharded
         self.metric = _native.METRIC_IP if metric in ("ip", "inner_product") else _native.METRIC_COSINE
         self.dim: Optional[int] = None
         self._index: Optional[_native.NativeIndex] = None
@@ -286,7 +288,11 @@ class DenseIndex:
     def _ensure_index(self, dim: int) -> None:
         if self._index is None:
             self.dim = int(dim)
-            self._index = _native.NativeIndex(self.dim, self.device)
+            if self.devices and len(self.devices) > 1:
+                from .distributed import MultiDeviceIndex
+                self._index = MultiDeviceIndex(self.dim, self.devices)
+            else:
+                self._index = _native.NativeIndex(self.dim, self.devices[0] if self.devices else self.device)
         elif dim != self.dim:
             raise ValueError(f"embedding dimension {dim} does not match the index ({self.dim})")
 
@@ -364,6 +370,8 @@ class DenseIndex:
         docs_path, base = self._files()
         docs_path.parent.mkdir(parents=True, exist_ok=True)
         if self._index is not None:
+            if not hasattr(self._index, "save"):
+                raise NotImplementedError("persistence of a multi-device index: save each shard's rows with rq_save, or rebuild")
             self._index.save(str(base))
         with open(docs_path, "w") as f:
             for i, doc_id in enumerate(self._ids):

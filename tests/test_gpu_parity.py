@@ -384,3 +384,66 @@ def test_option_validation_and_status_codes():
     with pytest.raises(nat.RqError):
         idx.get_rows_f16(0, 1)              # outside the (empty) index
     idx.close()
+
+
+def test_sharded_searcher_over_rccl_world_of_one():
+    """rag_uq_amd.distributed.ShardedDenseSearcher with a real nccl (= RCCL) process group: world size 1 here
+    (the box has one GPU); the 2-rank exchange + merge is covered on gloo in test_distributed_cpu.py and the
+    two-shards-on-one-GPU device merge above."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from rag_uq_amd import distributed as d
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        x16 = orc.synthetic_corpus(30_000, 768, seed=41)
+        idx = nat.NativeIndex(768, 0)
+        idx.add_f16(x16)
+        idx.set_row_offset(1_000)                       # this rank's block starts at global row 1000
+        searcher = d.ShardedDenseSearcher(idx)
+        q = orc.synthetic_queries(64, 768, seed=42)
+        scores, rows = searcher.search_device(torch.from_numpy(q).to(dev), 10)
+        torch.cuda.synchronize()
+        gs, gr = orc.dense_topk(q, x16, 10, row_offset=1_000)
+        assert np.array_equal(rows.cpu().numpy(), gr) and float(np.abs(scores.cpu().numpy() - gs).max()) <= SCORE_TOL
+        # the all_gather + merge leg on a single rank: gather of one list, merge must be the identity
+        keys = torch.from_numpy(d.pack_keys(gs, gr).view(np.int64)).to(dev)
+        gathered = torch.empty((1, 64, 10), device=dev, dtype=torch.int64)
+        dist.all_gather_into_tensor(gathered, keys)
+        ms = torch.empty((64, 10), device=dev); mr = torch.empty((64, 10), device=dev, dtype=torch.int64)
+        nat.merge_keys_device(gathered.permute(1, 0, 2).contiguous(), 10, 64, 10, ms, mr, None, 0)
+        torch.cuda.synchronize()
+        assert np.array_equal(mr.cpu().numpy(), gr)
+        idx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_multi_device_index_in_one_process():
+    """rows block-distributed over several 'devices' of one process (here the same GPU twice / three times):
+    segment mapping, host merge, incremental appends, duplicates across shards"""
+    from rag_uq_amd import distributed as d
+    from rag_uq_amd import streaming_index as si
+    x16 = orc.synthetic_corpus(9_001, 768, seed=51)
+    x16[4_400:4_600] = x16[17]
+    mdi = d.MultiDeviceIndex(768, [0, 0, 0])
+    mdi.add_f16(x16[:1_000]); mdi.add_f16(x16[1_000:1_001]); mdi.add_f16(x16[1_001:])
+    assert len(mdi) == 9_001
+    q = orc.synthetic_queries(70, 768, seed=52); q[0] = x16[17].astype(np.float32)
+    for k in (10, 250):
+        s, r = mdi.search(q, k)
+        gs, gr = orc.dense_topk(q, x16, k)
+        assert np.array_equal(r, gr) and float(np.abs(s - gs).max()) <= SCORE_TOL
+    mdi.close()
+    # through the reference-shaped class
+    from rag_uq_amd.embedders import HashEmbedder
+    docs = [si.Document(id=f"p{i}", text=f"passage {i} item {i * 37 % 211}") for i in range(400)]
+    one = si.DenseIndex(persist_directory="/tmp/rq_md_1", embedder=HashEmbedder(), load_persisted=False)
+    many = si.DenseIndex(persist_directory="/tmp/rq_md_2", embedder=HashEmbedder(), devices=[0, 0], load_persisted=False)
+    one.add_documents(docs); many.add_documents(docs[:150]); many.add_documents(docs[150:])
+    for text in ["passage 7 item 48", "item 100", docs[333].text]:
+        assert one.search(text, 25) == many.search(text, 25)
