@@ -31,7 +31,7 @@ DIM = 768
 BATCH = 64
 TOPK = 10
 N_QUERY_BATCHES = 16          # distinct query batches cycled through the steps
-GATHER_EVERY = 8              # batches per all-gather (N > 1)
+GATHER_EVERY = int(os.environ.get("RQ_BENCH_GATHER_EVERY", "16"))   # batches per all-gather (N > 1)
 CHUNK_ROWS = 125_000          # corpus generated in chunks seeded by global chunk id: same corpus for any N
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 

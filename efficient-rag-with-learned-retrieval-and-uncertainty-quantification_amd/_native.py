@@ -61,6 +61,7 @@ _SIGNATURES = {
     "rq_search_flush_device": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rq_merge_keys_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
+    "rq_debug_pooled": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     "rq_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
     "rq_get_option": (C.c_double, [C.c_void_p, C.c_char_p]),
     "rq_get_timing": (C.c_int, [C.c_void_p, C.POINTER(rq_timing)]),
@@ -212,6 +213,11 @@ class NativeIndex:
 
     def search_flush_device(self, stream: int = 0) -> None:
         _check(self._lib.rq_search_flush_device(self._h, C.c_void_p(stream)), "rq_search_flush_device")
+
+    def debug_pooled(self, query: int, max_bins: int, stream: int = 0) -> np.ndarray:
+        out = np.empty((int(max_bins),), dtype=np.float32)
+        n = _check(self._lib.rq_debug_pooled(self._h, C.c_void_p(stream), int(query), _ptr(out), int(max_bins)), "rq_debug_pooled")
+        return out[:n]
 
     # -- knobs / timing -----------------------------------------------------------------------
     def set_option(self, name: str, value: float) -> None:

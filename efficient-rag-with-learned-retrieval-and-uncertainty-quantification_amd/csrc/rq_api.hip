@@ -139,6 +139,7 @@ static int grow(rq_index* idx, int64_t want_rows) {
     while (cap < want_rows) cap *= 2;
     if (want_rows > (int64_t)1 << 27 && cap > want_rows + want_rows / 8) cap = want_rows + want_rows / 8;   // big shards: 12% headroom
     cap = (cap + 63) / 64 * 64;
+    HIPCHK(hipDeviceSynchronize());   // searches in flight on any stream still read the old buffers
     char* nx = nullptr; double* nn = nullptr; float* ni = nullptr;
     hipError_t e = hipMalloc((void**)&nx, (size_t)cap * RQ_DPAD * 2);
     if (e != hipSuccess) return set_err(RQ_ENOMEM, "hipMalloc of %lld corpus rows failed: %s", (long long)cap, hipGetErrorString(e));
@@ -354,9 +355,10 @@ extern "C" double rq_get_option(const rq_index* idx, const char* name) {
 }
 
 // ---- search ----------------------------------------------------------------------------------
+// (Re)allocate a device buffer of want_elems elements; the old contents are dropped.  hipFree waits for the
+// device, so kernels still using the old buffer have finished.
 template <class T>
-static int ensure(T*& p, size_t have_elems, size_t want_elems) {
-    if (p && have_elems >= want_elems) return RQ_OK;
+static int ensure(T*& p, size_t want_elems) {
     if (p) (void)hipFree(p);
     p = nullptr;
     hipError_t e = hipMalloc((void**)&p, want_elems * sizeof(T));
@@ -364,34 +366,34 @@ static int ensure(T*& p, size_t have_elems, size_t want_elems) {
     return RQ_OK;
 }
 
-static int ensure_ws(rq_index* idx, Workspace& w, int bpad, int64_t stride, int64_t m, int64_t ncand) {
+static int ensure_ws(Workspace& w, int bpad, int64_t stride, int64_t m, int64_t ncand) {
     const bool regrow_b = bpad > w.bcap;
     const int bcap = std::max(bpad, w.bcap);
     if (regrow_b) {
-        if (int r = ensure(w.qh, 0, (size_t)bcap * RQ_DPAD)) return r;
-        if (int r = ensure(w.q32, 0, (size_t)bcap * RQ_DPAD)) return r;
-        if (int r = ensure(w.qn, 0, (size_t)bcap)) return r;
-        if (int r = ensure(w.wgmax, 0, (size_t)bcap * RQ_WGMAX_STRIDE)) return r;
-        if (int r = ensure(w.binlist, 0, (size_t)bcap * RQ_FAST_MAX_BINS)) return r;
-        if (int r = ensure(w.bincount, 0, (size_t)bcap)) return r;
-        if (int r = ensure(w.thr, 0, (size_t)bcap)) return r;
-        if (int r = ensure(w.done, 0, (size_t)bcap)) return r;
-        if (int r = ensure(w.ovf, 0, (size_t)bcap)) return r;
+        if (int r = ensure(w.qh, (size_t)bcap * RQ_DPAD)) return r;
+        if (int r = ensure(w.q32, (size_t)bcap * RQ_DPAD)) return r;
+        if (int r = ensure(w.qn, (size_t)bcap)) return r;
+        if (int r = ensure(w.wgmax, (size_t)bcap * RQ_WGMAX_STRIDE)) return r;
+        if (int r = ensure(w.binlist, (size_t)bcap * RQ_FAST_MAX_BINS)) return r;
+        if (int r = ensure(w.bincount, (size_t)bcap)) return r;
+        if (int r = ensure(w.thr, (size_t)bcap)) return r;
+        if (int r = ensure(w.done, (size_t)bcap)) return r;
+        if (int r = ensure(w.ovf, (size_t)bcap)) return r;
         w.bincount_zero = w.done_zero = w.ovf_zero = false;
     }
     if (regrow_b || stride > w.pooled_stride) {
         const int64_t st = std::max(stride, w.pooled_stride);
-        if (int r = ensure(w.pooled, 0, (size_t)bcap * st)) return r;
+        if (int r = ensure(w.pooled, (size_t)bcap * st)) return r;
         w.pooled_stride = st;
     }
     if (regrow_b || m > w.binkeys_cap) {
         const int64_t mm = std::max(m, w.binkeys_cap);
-        if (int r = ensure(w.binkeys, 0, (size_t)bcap * mm)) return r;
+        if (int r = ensure(w.binkeys, (size_t)bcap * mm)) return r;
         w.binkeys_cap = mm;
     }
     if (regrow_b || ncand > w.cand_cap) {
         const int64_t nc = std::max(ncand, w.cand_cap);
-        if (int r = ensure(w.cand, 0, (size_t)bcap * nc)) return r;
+        if (int r = ensure(w.cand, (size_t)bcap * nc)) return r;
         w.cand_cap = nc;
     }
     w.bcap = bcap;
@@ -467,7 +469,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
         if (int r = flush_tails(idx, s)) return r;   // order after anything still on the tail stream
     }
     Workspace& w = cx.w[par];
-    if (int r = ensure_ws(idx, w, bpad, exact ? 64 : stride, exact ? 1 : m, ncand)) return r;
+    if (int r = ensure_ws(w, bpad, exact ? 64 : stride, exact ? 1 : m, ncand)) return r;
     const float* scale = idx->inv_norm;
     if (metric == RQ_METRIC_IP) { if (int r = ensure_ones(idx, s)) return r; scale = idx->ones; }
 
@@ -622,11 +624,11 @@ extern "C" int rq_search_fixup_device(rq_index* idx, const float* d_queries, int
     const int fb = (int)bad.size();
     if (fb > w.fix_bcap || k > w.fix_k) {
         const int nb_ = std::max(fb, w.fix_bcap), nk = std::max(k, w.fix_k);
-        if (int r = ensure(w.fix_q, 0, (size_t)nb_ * RQ_MAX_DIM)) return r;
-        if (int r = ensure(w.fix_scores, 0, (size_t)nb_ * nk)) return r;
-        if (int r = ensure(w.fix_rows, 0, (size_t)nb_ * nk)) return r;
-        if (int r = ensure(w.fix_keys, 0, (size_t)nb_ * nk)) return r;
-        if (int r = ensure(w.fix_status, 0, (size_t)nb_)) return r;
+        if (int r = ensure(w.fix_q, (size_t)nb_ * RQ_MAX_DIM)) return r;
+        if (int r = ensure(w.fix_scores, (size_t)nb_ * nk)) return r;
+        if (int r = ensure(w.fix_rows, (size_t)nb_ * nk)) return r;
+        if (int r = ensure(w.fix_keys, (size_t)nb_ * nk)) return r;
+        if (int r = ensure(w.fix_status, (size_t)nb_)) return r;
         w.fix_bcap = nb_; w.fix_k = nk;
     }
     // ladder: 4x wider candidate set, then the full fp64 scan
@@ -678,10 +680,10 @@ extern "C" int rq_search(rq_index* idx, const float* queries, int B, int k, int 
     if (int r = use_device(idx)) return r;
     if (B > idx->h_bcap || k > idx->h_kcap) {
         const int nb = std::max(B, idx->h_bcap), nk = std::max(k, idx->h_kcap);
-        if (int r = ensure(idx->h_dq, 0, (size_t)nb * RQ_MAX_DIM)) return r;
-        if (int r = ensure(idx->h_dscores, 0, (size_t)nb * nk)) return r;
-        if (int r = ensure(idx->h_drows, 0, (size_t)nb * nk)) return r;
-        if (int r = ensure(idx->h_dstatus, 0, (size_t)nb)) return r;
+        if (int r = ensure(idx->h_dq, (size_t)nb * RQ_MAX_DIM)) return r;
+        if (int r = ensure(idx->h_dscores, (size_t)nb * nk)) return r;
+        if (int r = ensure(idx->h_drows, (size_t)nb * nk)) return r;
+        if (int r = ensure(idx->h_dstatus, (size_t)nb)) return r;
         idx->h_bcap = nb; idx->h_kcap = nk;
     }
     hipStream_t s = idx->own_stream;
@@ -700,6 +702,21 @@ extern "C" int rq_merge_keys_device(const uint64_t* d_keys_in, int n_per_query, 
     if (!d_keys_in || !d_scores || !d_rows || B < 1 || k < 1 || k > RQ_MAX_K || n_per_query < 0) return set_err(RQ_EINVAL, "bad merge arguments");
     HIPCHK(rq_merge_keys_launch(d_keys_in, n_per_query, B, k, d_scores, d_rows, d_keys_out, (hipStream_t)stream));
     return RQ_OK;
+}
+
+// ---- test hook: the scan's per-bin maxima of the last search on `stream` ---------------------------------
+extern "C" int64_t rq_debug_pooled(rq_index* idx, void* stream, int query, float* out, int64_t max_bins) {
+    if (!idx || !out || query < 0) return set_err(RQ_EINVAL, "bad arguments");
+    if (int r = use_device(idx)) return r;
+    auto it = idx->ctx.find((hipStream_t)stream);
+    if (it == idx->ctx.end() || !it->second.w[0].pooled || query >= it->second.w[0].bcap) return set_err(RQ_EINVAL, "no search has run on this stream");
+    const Workspace& w = it->second.w[0];
+    const int per_quad = 16 / idx->bin_tiles;
+    const int64_t nbins = ((idx->n + 63) / 64) * per_quad;
+    const int64_t n = std::min(nbins, max_bins);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, w.pooled + (size_t)query * w.pooled_stride, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return n;
 }
 
 // ---- timing ----------------------------------------------------------------------------------

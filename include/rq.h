@@ -121,6 +121,10 @@ int rq_reset_timing(rq_index* idx);
 int rq_save(const rq_index* idx, const char* path);
 rq_index* rq_load(const char* path, int n_devices, const int* device_ids);
 
+/* Test hook: copy the scan's approximate per-bin maxima of query `query` of the LAST search enqueued on `stream`
+ * (bin b of 4*bin_tiles rows, see csrc/rq_device.h rq_bin_row) to the host.  Returns the number of bins copied. */
+int64_t rq_debug_pooled(rq_index* idx, void* stream, int query, float* out, int64_t max_bins);
+
 const char* rq_last_error(void);
 const char* rq_version(void);
 

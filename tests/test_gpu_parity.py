@@ -447,3 +447,46 @@ def test_multi_device_index_in_one_process():
     one.add_documents(docs); many.add_documents(docs[:150]); many.add_documents(docs[150:])
     for text in ["passage 7 item 48", "item 100", docs[333].text]:
         assert one.search(text, 25) == many.search(text, 25)
+
+
+@pytest.mark.parametrize("bin_tiles", [4, 2, 1])
+def test_scan_bin_maxima_within_certificate_eps(bin_tiles):
+    """The certificate assumes |approximate scan score - exact score| <= eps = 7e-4.  Read the
+    scan's per-bin maxima back and compare them with the exact per-bin maxima from the oracle: validates the MFMA
+    fragment layout, the LDS swizzle, the bin <-> row mapping (rq_bin_row) and the bound itself."""
+    import torch
+    n, B = 40_000, 64
+    x16 = orc.synthetic_corpus(n, 768, seed=61)
+    x16[5] = 0
+    q = orc.synthetic_queries(B, 768, seed=62) * 17.0
+    q[3] = x16[100].astype(np.float32)
+    idx = nat.NativeIndex(768, 0)
+    idx.add_f16(x16)
+    idx.set_option("bin_tiles", bin_tiles)
+    dev = torch.device("cuda:0")
+    dq = torch.from_numpy(q).to(dev)
+    sc = torch.empty((B, 10), device=dev); rw = torch.empty((B, 10), device=dev, dtype=torch.int64); st = torch.empty((B,), device=dev, dtype=torch.int32)
+    idx.search_device(dq, B, 10, 0, sc, rw, None, st, 0)
+    torch.cuda.synchronize()
+    exact = orc.exact_scores(q, x16)                                   # [B][n] canonical fp32
+    R = bin_tiles
+    nbins = ((n + 63) // 64) * (16 // R)
+    # rows of every bin, straight from the definition in csrc/rq_device.h
+    b = np.arange(nbins)
+    per_quad, per_kg = 16 // R, 4 // R
+    quad, rem = b // per_quad, b % per_quad
+    kg, u = rem // per_kg, rem % per_kg
+    j = np.arange(4 * R)
+    rows = quad[:, None] * 64 + 16 * (u[:, None] * R + (j // 4)[None, :]) + 4 * kg[:, None] + (j % 4)[None, :]
+    valid = rows < n
+    worst = 0.0
+    for qi in (0, 3, 17, 63):
+        pooled = idx.debug_pooled(qi, nbins)
+        assert pooled.shape == (nbins,)
+        e = np.where(valid, exact[qi][np.minimum(rows, n - 1)], -np.inf).max(axis=1)
+        ok = np.isfinite(e)
+        assert np.array_equal(np.isfinite(pooled), ok)
+        worst = max(worst, float(np.abs(pooled[ok] - e[ok]).max()))
+    assert worst <= 7e-4, worst
+    assert worst <= 1e-4, f"observed error {worst} is far above the ~1e-5 expected from fp16 query rounding"
+    idx.close()
