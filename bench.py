@@ -189,6 +189,16 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     timing = idx.timing()
+    # calibration outside the timed region: the same launches on ONE stream (no overlap with a second scan), so the
+    # stand-alone duration of the kernel can be read next to the live one
+    idx.reset_timing()
+    for i in range(24):
+        o = slots[i % N_QUERY_BATCHES]
+        idx.search_device(queries[i % N_QUERY_BATCHES], B, k, nat.METRIC_COSINE, o["scores"], o["rows"], o["keys"], o["status"],
+                          streams[0].cuda_stream)
+    torch.cuda.synchronize()
+    iso = idx.timing()
+    iso_us = iso["scan_ms"] * 1e3 / max(iso["scan_launches"], 1)
     idx.set_option("profile", 0)
 
     qps = args.steps * B / elapsed
@@ -221,7 +231,11 @@ def main() -> None:
                    "parallelism": f"row-shard x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "rq_scan_kernel",
-                     "avg_launch_us": scan_us, "launches": timing["scan_launches"], "algorithmic_bytes_per_launch": algo_bytes},
+                     "avg_launch_us": scan_us, "launches": timing["scan_launches"], "algorithmic_bytes_per_launch": algo_bytes,
+                     "isolated": {"avg_launch_us": iso_us, "achieved": algo_bytes / (iso_us * 1e-6) / 1e9 if iso_us > 0 else 0.0,
+                                  "frac": (algo_bytes / (iso_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if iso_us > 0 else 0.0,
+                                  "note": "same kernel, 24 launches on one stream after the timed region; the live figure above "
+                                          "is taken while two streams overlap, which stretches every launch"}},
         "repaired_queries": fixed,
         "exact_scans": timing["exact_scans"],
     }
