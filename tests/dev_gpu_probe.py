@@ -1,4 +1,4 @@
-"""Development probe (run on the GPU box): parity on small shapes, then scan-variant timings at 1M rows."""
+"""Development probe, kept under tests/ because it checks against the oracle (run on the GPU box): parity on small shapes, then scan-variant timings at 1M rows."""
 import importlib.util, json, os, sys, time
 import numpy as np
 
