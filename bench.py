@@ -277,6 +277,32 @@ def main() -> None:
                                "sample": f"{nb} batches of {B} queries over the full {n_local}x{DIM} corpus, oracle/dense_oracle.py "
                                          f"Fp32BruteForce variant '{best}' (fp32 OpenBLAS GEMM + argpartition; one-batch trials: "
                                          + ", ".join(f"{n_}: {t_ * 1e3:.0f} ms" for n_, t_ in trial.items()) + ")"}
+    if use_comm:
+        # N > 1 correctness evidence (outside the timed region): GPU path = per-shard search -> RCCL all-gather ->
+        # device merge; checker = every rank's ORACLE top-k of its own shard -> all-gather -> host merge.
+        from oracle import dense_oracle as orc
+        from rag_uq_amd import distributed as rqd
+        nchk = 4
+        o = slots[0]
+        idx.search_device(queries[0], B, k, nat.METRIC_COSINE, o["scores"], o["rows"], o["keys"], o["status"], 0)
+        idx.search_fixup_device(queries[0], B, k, nat.METRIC_COSINE, o["scores"], o["rows"], o["keys"], o["status"], 0)
+        allk = torch.zeros((world, B, k), device=dev, dtype=torch.int64)
+        dist.all_gather_into_tensor(allk, o["keys"])
+        g_scores = torch.empty((B, k), device=dev)
+        g_rows = torch.empty((B, k), device=dev, dtype=torch.int64)
+        nat.merge_keys_device(allk.permute(1, 0, 2).contiguous(), world * k, B, k, g_scores, g_rows, None, 0)
+        torch.cuda.synchronize()
+        q_host = queries[0][:nchk].cpu().numpy()
+        ls, lr = orc.dense_topk(q_host, idx.get_rows_f16(0, n_local), k, row_offset=row_lo) if n_local else (
+            np.zeros((nchk, k), np.float32), np.full((nchk, k), -1, np.int64))
+        okeys = torch.from_numpy(rqd.pack_keys(ls, lr).view(np.int64).copy()).to(dev)
+        oall = torch.zeros((world, nchk, k), device=dev, dtype=torch.int64)
+        dist.all_gather_into_tensor(oall, okeys)
+        ms, mr = rqd.merge_keys_host(oall.permute(1, 0, 2).reshape(nchk, world * k).cpu().numpy().view(np.uint64), k)
+        got_r = g_rows[:nchk].cpu().numpy()
+        out["recall_at_10"] = orc.recall_at_k(got_r, mr)
+        out["ids_exact"] = bool((got_r == mr).all())
+        out["max_abs_score_err"] = float(np.abs(g_scores[:nchk].cpu().numpy() - ms).max())
     if rank == 0:
         print(json.dumps(out), flush=True)
     idx.close()
