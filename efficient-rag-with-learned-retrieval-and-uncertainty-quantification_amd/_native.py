@@ -15,7 +15,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 _PKG_DIR = Path(__file__).resolve().parent
-LIB_PATH = _PKG_DIR / "librq_hip.so"
+LIB_PATH = Path(os.environ["RQ_LIB_PATH"]) if os.environ.get("RQ_LIB_PATH") else _PKG_DIR / "librq_hip.so"   # override: A/B of builds
 
 METRIC_COSINE = 0
 METRIC_IP = 1

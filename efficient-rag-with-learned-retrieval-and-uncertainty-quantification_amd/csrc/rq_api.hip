@@ -55,12 +55,12 @@ struct Workspace {
     uint64_t* binkeys = nullptr;
     uint64_t* cand = nullptr;
     float* wgmax = nullptr;       // [bcap][RQ_WGMAX_STRIDE]
-    int* binlist = nullptr;       // [bcap][RQ_FAST_MAX_BINS]
-    int* bincount = nullptr;      // [bcap]
+    uint32_t* aux = nullptr;      // [bcap][pooled_stride] second-largest score (16-bit upper bound) | arg-max position per bin
+    int* rowcount = nullptr;      // [bcap] fast tail: candidate rows appended so far
     float* thr = nullptr;         // [bcap]
-    int* done = nullptr;          // [bcap] fused tail: workgroups of the query that have finished
-    int* ovf = nullptr;           // [bcap] fused tail: a workgroup found more bins than it could hold
-    bool bincount_zero = false, done_zero = false, ovf_zero = false;   // counters known to be all zero right now
+    int* done = nullptr;          // [bcap] fast tail: workgroups of the query that have finished
+    int* ovf = nullptr;           // [bcap] fast tail: a workgroup found more bins / rows than it could hold
+    bool counters_zero = false;   // rowcount/done/ovf known to be all zero (the tail kernel leaves them so)
     // staging for rq_search_fixup_device
     int fix_bcap = 0, fix_k = 0;
     float* fix_q = nullptr;
@@ -92,7 +92,7 @@ struct rq_index {
     double* d_maxnorm = nullptr;   // device scalar, bits of the running max row norm
     double max_row_norm = 0.0;
     // options
-    int ring = 4, prefetch = 4, kstage = 2, wide_batch = 1, bin_tiles = 4, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, fast_tail = 1, pipeline = 0, fused_tail = 1, tail_stop = 0;
+    int ring = 4, prefetch = 4, kstage = 2, wide_batch = 1, bin_tiles = 4, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, fast_tail = 1, pipeline = 0, tail_stop = 0;
     double eps = -1.0;
     std::map<hipStream_t, StreamCtx> ctx;
     hipStream_t own_stream = nullptr;
@@ -198,7 +198,7 @@ extern "C" rq_index* rq_index_create(int dim, int n_devices, const int* device_i
 }
 
 static void free_ws(Workspace& w) {
-    void* p[] = {w.qh, w.q32, w.qn, w.pooled, w.binkeys, w.cand, w.wgmax, w.binlist, w.bincount, w.thr, w.done, w.ovf, w.fix_q, w.fix_scores, w.fix_rows, w.fix_keys, w.fix_status};
+    void* p[] = {w.qh, w.q32, w.qn, w.pooled, w.binkeys, w.cand, w.wgmax, w.aux, w.rowcount, w.thr, w.done, w.ovf, w.fix_q, w.fix_scores, w.fix_rows, w.fix_keys, w.fix_status};
     for (void* q : p) if (q) (void)hipFree(q);
     w = Workspace();
 }
@@ -328,7 +328,6 @@ extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     else if (s == "profile") idx->profile = (int)v;
     else if (s == "fast_tail") idx->fast_tail = (int)v;
     else if (s == "pipeline") idx->pipeline = (int)v;
-    else if (s == "fused_tail") idx->fused_tail = (int)v;
     else if (s == "tail_stop") idx->tail_stop = (int)v;
     else return set_err(RQ_EINVAL, "unknown option '%s'", name);
     return RQ_OK;
@@ -348,7 +347,6 @@ extern "C" double rq_get_option(const rq_index* idx, const char* name) {
     if (s == "profile") return idx->profile;
     if (s == "fast_tail") return idx->fast_tail;
     if (s == "pipeline") return idx->pipeline;
-    if (s == "fused_tail") return idx->fused_tail;
     if (s == "cu_count") return idx->cu_count;
     if (s == "max_row_norm") return idx->max_row_norm;
     return NAN;
@@ -374,16 +372,16 @@ static int ensure_ws(Workspace& w, int bpad, int64_t stride, int64_t m, int64_t 
         if (int r = ensure(w.q32, (size_t)bcap * RQ_DPAD)) return r;
         if (int r = ensure(w.qn, (size_t)bcap)) return r;
         if (int r = ensure(w.wgmax, (size_t)bcap * RQ_WGMAX_STRIDE)) return r;
-        if (int r = ensure(w.binlist, (size_t)bcap * RQ_FAST_MAX_BINS)) return r;
-        if (int r = ensure(w.bincount, (size_t)bcap)) return r;
+        if (int r = ensure(w.rowcount, (size_t)bcap)) return r;
         if (int r = ensure(w.thr, (size_t)bcap)) return r;
         if (int r = ensure(w.done, (size_t)bcap)) return r;
         if (int r = ensure(w.ovf, (size_t)bcap)) return r;
-        w.bincount_zero = w.done_zero = w.ovf_zero = false;
+        w.counters_zero = false;
     }
     if (regrow_b || stride > w.pooled_stride) {
         const int64_t st = std::max(stride, w.pooled_stride);
         if (int r = ensure(w.pooled, (size_t)bcap * st)) return r;
+        if (int r = ensure(w.aux, (size_t)bcap * st)) return r;
         w.pooled_stride = st;
     }
     if (regrow_b || m > w.binkeys_cap) {
@@ -447,9 +445,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     const int64_t stride = (nbins + 63) / 64 * 64;
     const int m = nb + 1;
     const bool fast = !exact && idx->fast_tail && m <= RQ_FAST_MAX_M && k <= RQ_FAST_MAX_K;
-    int rmax = 0;
-    if (fast) { rmax = std::min(RQ_FAST_MAX_BINS, std::max(32, 2 * m)); rmax = (rmax + 7) / 8 * 8; }
-    const int64_t ncand = fast ? (int64_t)rmax * binrows : (int64_t)nb * binrows;
+    const int64_t ncand = fast ? (int64_t)RQ_CAND_CAP : (int64_t)nb * binrows;
     StreamCtx& cx = idx->ctx[s];
     const bool piped = fast && idx->pipeline != 0;
     int par = 0;
@@ -473,15 +469,15 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     const float* scale = idx->inv_norm;
     if (metric == RQ_METRIC_IP) { if (int r = ensure_ones(idx, s)) return r; scale = idx->ones; }
 
-    const bool fused = fast && idx->fused_tail != 0;        // one tail kernel (0: collect / re-score / final as three kernels)
-    // counter protocol: the fused tail needs bincount/done/ovf zero on entry and leaves them zero; the three-kernel
-    // tail has its bincount zeroed by the query-preparation kernel and leaves it dirty.
-    if (fused && !w.done_zero) { HIPCHK(hipMemsetAsync(w.done, 0, (size_t)w.bcap * sizeof(int), s)); w.done_zero = true; }
-    if (fused && !w.bincount_zero) { HIPCHK(hipMemsetAsync(w.bincount, 0, (size_t)w.bcap * sizeof(int), s)); w.bincount_zero = true; }
-    if (fused && !w.ovf_zero) { HIPCHK(hipMemsetAsync(w.ovf, 0, (size_t)w.bcap * sizeof(int), s)); w.ovf_zero = true; }
-    // unit-norm fp16 query fragments for the scan (+ padded fp32 queries / fp64 norms for the non-fused tails)
-    HIPCHK(rq_prep_queries_launch(d_q, idx->dim, B, bpad, w.qh, w.q32, w.qn, fused ? nullptr : w.bincount, s));
-    if (!fused) w.bincount_zero = false;
+    // counter protocol of the tail kernel: rowcount/done/ovf are zero on entry and the kernel leaves them zero
+    if (fast && !w.counters_zero) {
+        HIPCHK(hipMemsetAsync(w.rowcount, 0, (size_t)w.bcap * sizeof(int), s));
+        HIPCHK(hipMemsetAsync(w.done, 0, (size_t)w.bcap * sizeof(int), s));
+        HIPCHK(hipMemsetAsync(w.ovf, 0, (size_t)w.bcap * sizeof(int), s));
+        w.counters_zero = true;
+    }
+    // unit-norm fp16 query fragments for the scan (+ padded fp32 queries / fp64 norms for the generic tail)
+    HIPCHK(rq_prep_queries_launch(d_q, idx->dim, B, bpad, w.qh, w.q32, w.qn, s));
     const int grid = (int)std::min<int64_t>(std::min<int64_t>(nquads, RQ_WGMAX_STRIDE),
                                             (int64_t)idx->cu_count * (qb == 128 ? 1 : idx->wg_per_cu));
     if (!exact) {
@@ -494,6 +490,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             a.row_scale = scale;
             a.qh = w.qh + (size_t)blk * qb * RQ_DPAD;
             a.pooled = w.pooled + (size_t)blk * qb * w.pooled_stride;
+            a.aux = w.aux + (size_t)blk * qb * w.pooled_stride;
             a.pooled_stride = w.pooled_stride;
             a.n_rows = idx->n;
             a.nquads = nquads;
@@ -521,48 +518,29 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
                 HIPCHK(hipStreamWaitEvent(cx.tail, cx.ev_scan[par], 0));
                 ts = cx.tail;
             }
-            if (fused) {
-                RqTailArgs ta;
-                ta.q = d_q; ta.dim = idx->dim; ta.x = idx->x; ta.rownorm64 = idx->rownorm64; ta.n_rows = idx->n;
-                ta.pooled = w.pooled; ta.pooled_stride = w.pooled_stride; ta.nbins = nbins;
-                ta.wgmax = w.wgmax; ta.wgmax_stride = RQ_WGMAX_STRIDE; ta.nwg = grid;
-                ta.m = m; ta.rmax = rmax; ta.R = R; ta.metric = metric; ta.k = k;
-                ta.eps = idx->eps < 0 ? RQ_EPS_DEFAULT : (float)idx->eps;
-                ta.max_row_norm = (float)(idx->max_row_norm * (1.0 + 1e-6)); ta.row_offset = idx->row_offset;
-                ta.cand = w.cand; ta.bincount = w.bincount; ta.done = w.done; ta.ovf = w.ovf;
-                ta.out_scores = d_scores; ta.out_rows = d_rows; ta.out_keys = d_keys; ta.out_status = d_status;
-                ta.stop_after = idx->tail_stop;
-                if (idx->tail_stop) w.bincount_zero = w.done_zero = w.ovf_zero = false;   // a truncated tail does not reset its counters
-                const bool tprof = idx->profile == 2 && idx->ev_used < 16384;   // profile = 2: time the tail instead of the scan
-                if (tprof) {
-                    if (idx->ev_used == idx->events.size()) {
-                        hipEvent_t e0, e1;
-                        HIPCHK(hipEventCreate(&e0));
-                        HIPCHK(hipEventCreate(&e1));
-                        idx->events.push_back({e0, e1});
-                    }
-                    HIPCHK(hipEventRecord(idx->events[idx->ev_used].first, ts));
+            RqTailArgs ta;
+            ta.q = d_q; ta.dim = idx->dim; ta.x = idx->x; ta.rownorm64 = idx->rownorm64; ta.n_rows = idx->n;
+            ta.pooled = w.pooled; ta.aux = w.aux; ta.pooled_stride = w.pooled_stride; ta.nbins = nbins;
+            ta.wgmax = w.wgmax; ta.wgmax_stride = RQ_WGMAX_STRIDE; ta.nwg = grid;
+            ta.m = m; ta.R = R; ta.metric = metric; ta.k = k;
+            ta.eps = idx->eps < 0 ? RQ_EPS_DEFAULT : (float)idx->eps;
+            ta.max_row_norm = (float)(idx->max_row_norm * (1.0 + 1e-6)); ta.row_offset = idx->row_offset;
+            ta.cand = w.cand; ta.rowcount = w.rowcount; ta.done = w.done; ta.ovf = w.ovf;
+            ta.out_scores = d_scores; ta.out_rows = d_rows; ta.out_keys = d_keys; ta.out_status = d_status;
+            ta.stop_after = idx->tail_stop;
+            if (idx->tail_stop) w.counters_zero = false;   // a truncated tail does not reset its counters
+            const bool tprof = idx->profile == 2 && idx->ev_used < 16384;   // profile = 2: time the tail instead of the scan
+            if (tprof) {
+                if (idx->ev_used == idx->events.size()) {
+                    hipEvent_t e0, e1;
+                    HIPCHK(hipEventCreate(&e0));
+                    HIPCHK(hipEventCreate(&e1));
+                    idx->events.push_back({e0, e1});
                 }
-                HIPCHK(rq_tail_launch(ta, B, ts));
-                if (tprof) { HIPCHK(hipEventRecord(idx->events[idx->ev_used].second, ts)); idx->ev_used++; }
-                if (piped) { HIPCHK(hipEventRecord(cx.ev_tail[par], cx.tail)); cx.tail_pending[par] = true; }
-                return RQ_OK;
+                HIPCHK(hipEventRecord(idx->events[idx->ev_used].first, ts));
             }
-            RqCollectArgs ca;
-            ca.pooled = w.pooled; ca.pooled_stride = w.pooled_stride; ca.nbins = nbins; ca.wgmax = w.wgmax;
-            ca.wgmax_stride = RQ_WGMAX_STRIDE; ca.nwg = grid; ca.m = m; ca.rmax = rmax; ca.binlist = w.binlist;
-            ca.bincount = w.bincount; ca.thr = w.thr;
-            HIPCHK(rq_collect_launch(ca, B, ts));
-            RqRescoreListArgs rl;
-            rl.x = idx->x; rl.q32 = w.q32; rl.qnorm64 = w.qn; rl.rownorm64 = idx->rownorm64; rl.binlist = w.binlist;
-            rl.bincount = w.bincount; rl.rmax = rmax; rl.R = R; rl.metric = metric; rl.n_rows = idx->n; rl.cand = w.cand;
-            HIPCHK(rq_rescore_list_launch(rl, B, ts));
-            RqFinalFastArgs ff;
-            ff.cand = w.cand; ff.bincount = w.bincount; ff.thr = w.thr; ff.rmax = rmax; ff.binrows = binrows; ff.qnorm64 = w.qn;
-            ff.metric = metric; ff.eps = idx->eps < 0 ? RQ_EPS_DEFAULT : (float)idx->eps;
-            ff.max_row_norm = (float)(idx->max_row_norm * (1.0 + 1e-6)); ff.k = k; ff.row_offset = idx->row_offset;
-            ff.n_rows = idx->n; ff.out_scores = d_scores; ff.out_rows = d_rows; ff.out_keys = d_keys; ff.out_status = d_status;
-            HIPCHK(rq_final_fast_launch(ff, B, ts));
+            HIPCHK(rq_tail_launch(ta, B, ts));
+            if (tprof) { HIPCHK(hipEventRecord(idx->events[idx->ev_used].second, ts)); idx->ev_used++; }
             if (piped) { HIPCHK(hipEventRecord(cx.ev_tail[par], cx.tail)); cx.tail_pending[par] = true; }
             return RQ_OK;
         }

@@ -41,6 +41,20 @@ __host__ __device__ static inline uint64_t rq_make_key(float score, uint32_t ind
 __host__ __device__ static inline float rq_key_score(uint64_t key) { return rq_unmono32((uint32_t)(key >> 32)); }
 __host__ __device__ static inline uint32_t rq_key_index(uint64_t key) { return 0xffffffffu - (uint32_t)(key & 0xffffffffu); }
 
+// Upper bound of a float in its 16 high bits: positive values round the magnitude up, negative ones truncate
+// (toward zero = up); -inf stays -inf.  The low 16 bits of the result are zero.
+__host__ __device__ static inline uint32_t rq_up16(float f) {
+    uint32_t u;
+    __builtin_memcpy(&u, &f, 4);
+    return (u & 0x80000000u) ? (u & 0xffff0000u) : ((u + 0xffffu) & 0xffff0000u);
+}
+__host__ __device__ static inline float rq_aux_second(uint32_t w) {
+    const uint32_t u = w & 0xffff0000u;
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+
 // Rows of bin `bin` for bins of 4*R rows (see rq_scan.hip for why bins look like this):
 //   per_quad = 16 / R bins per quad; inside a quad bin = kg * (4/R) + u,
 //   rows = quad*64 + 16*(u*R + tt) + 4*kg + i   for tt < R, i < 4.

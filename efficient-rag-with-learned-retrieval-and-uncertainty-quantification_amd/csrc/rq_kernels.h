@@ -8,6 +8,7 @@ struct RqScanArgs {
     const float* row_scale;   // [rows_padded] 1/||row|| (cosine) or 1.0 (inner product); pad entries 0
     const _Float16* qh;       // [QB][768] unit-norm fp16 queries of this block (QB = 64 or 128), unused slots zero
     float* pooled;            // [QB][pooled_stride] per-bin maxima of the approximate score
+    uint32_t* aux;            // [QB][pooled_stride] per bin: second-largest score (16-bit upper bound) | arg-max position
     int64_t pooled_stride;    // floats per query row, >= nquads * 16 / R
     int64_t n_rows;           // valid rows of the shard
     int nquads;               // ceil(n_rows / 64)
@@ -28,7 +29,7 @@ hipError_t rq_pad_f16_launch(const void* src, int dim, int64_t n, void* dst_rows
 
 // Query preparation: qnorm64[q] = ||q|| (fp64); qh = fp16(q/||q||) padded to 768, slots >= B zero.
 hipError_t rq_prep_queries_launch(const float* q, int dim, int B, int Bpad, _Float16* qh, float* q32pad, double* qnorm64,
-                                  int* bincount, hipStream_t stream);
+                                  hipStream_t stream);
 
 // Pass 2: per query, the m best bins of pooled[q][0..nbins) as sorted keys (score desc, bin asc); 0-padded.
 hipError_t rq_select_bins_launch(const float* pooled, int64_t pooled_stride, int64_t nbins, int B, int m,
@@ -72,44 +73,22 @@ struct RqFinalArgs {
 };
 hipError_t rq_final_launch(const RqFinalArgs& a, int B, hipStream_t stream);
 
-// ---- fast tail (m <= 128 bins, k <= 128): threshold from wgmax, unordered bin list, extraction top-k ----
+// ---- fast tail (the common case: m <= 128 bins wanted, k <= 128) ----
 #define RQ_FAST_MAX_M 128
 #define RQ_FAST_MAX_K 128
-#define RQ_FAST_MAX_BINS 256   // bin-list capacity per query (rmax <= this)
-struct RqCollectArgs {
-    const float* pooled; int64_t pooled_stride; int64_t nbins;
-    const float* wgmax; int wgmax_stride; int nwg;   // nwg = scan grid size
-    int m;                     // threshold = m-th largest per-workgroup maximum (valid: >= m bins reach it)
-    int rmax;                  // bin-list capacity per query
-    int* binlist;              // [B][rmax]
-    int* bincount;             // [B], zeroed by the query-preparation kernel
-    float* thr;                // [B]
-};
-hipError_t rq_collect_launch(const RqCollectArgs& a, int B, hipStream_t stream);
-struct RqRescoreListArgs {
-    const void* x; const float* q32; const double* qnorm64; const double* rownorm64;
-    const int* binlist; const int* bincount; int rmax; int R; int metric; int64_t n_rows;
-    uint64_t* cand;            // [B][rmax*4R]
-};
-hipError_t rq_rescore_list_launch(const RqRescoreListArgs& a, int B, hipStream_t stream);
-struct RqFinalFastArgs {
-    const uint64_t* cand; const int* bincount; const float* thr; int rmax; int binrows;
-    const double* qnorm64; int metric; float eps; float max_row_norm; int k; int64_t row_offset; int64_t n_rows;
-    float* out_scores; int64_t* out_rows; uint64_t* out_keys; int* out_status;
-};
-hipError_t rq_final_fast_launch(const RqFinalFastArgs& a, int B, hipStream_t stream);
+#define RQ_CAND_CAP 4096       // candidate keys per query (compact list written by the tail kernel)
 
 // Fused tail: threshold + bin collection + exact re-score + final top-k + certificate in one launch.
 struct RqTailArgs {
     const float* q; int dim;                       // raw fp32 queries [B][dim]
     const void* x; const double* rownorm64; int64_t n_rows;
-    const float* pooled; int64_t pooled_stride; int64_t nbins;
+    const float* pooled; const uint32_t* aux; int64_t pooled_stride; int64_t nbins;
     const float* wgmax; int wgmax_stride; int nwg;
-    int m, rmax, R, metric, k;
+    int m, R, metric, k;
     float eps, max_row_norm;
     int64_t row_offset;
-    uint64_t* cand;                                // [B][rmax*4R]
-    int* bincount; int* done; int* ovf;            // [B] each, zero before the launch, reset by the kernel
+    uint64_t* cand;                                // [B][RQ_CAND_CAP] compact candidate keys
+    int* rowcount; int* done; int* ovf;            // [B] each, zero before the launch, reset by the kernel
     float* out_scores; int64_t* out_rows; uint64_t* out_keys; int* out_status;
     int stop_after;                                // development: 0 = full kernel, 1..4 = return after phase A..D
 };

@@ -114,9 +114,10 @@ __global__ __launch_bounds__(64 * QW, OCC) void rq_scan_kernel(RqScanArgs a) {
 
     for (int lq = 0; lq < nloc; ++lq) {
         const int64_t quad = (int64_t)b + (int64_t)lq * G;
-        float binmax[4 / R];
+        float binmax[4 / R], bin2[4 / R];   // largest and second-largest approximate score of each bin of this lane
+        int binarg[4 / R];                  // position (0 .. 4R-1) of the largest inside its bin
 #pragma unroll
-        for (int u = 0; u < 4 / R; ++u) binmax[u] = NEG_INF;
+        for (int u = 0; u < 4 / R; ++u) { binmax[u] = NEG_INF; bin2[u] = NEG_INF; binarg[u] = 0; }
         const char* nrow = norm_lds + (((lq & 1) * QW + wave) << 8) + kg * 16;
 
 #pragma unroll
@@ -143,25 +144,38 @@ __global__ __launch_bounds__(64 * QW, OCC) void rq_scan_kernel(RqScanArgs a) {
             // tile epilogue: D[row = 4*kg + i][query = r16]
             const rq_float4 nv = *(const rq_float4*)(nrow + t * 64);
             const int64_t row0 = quad * RQ_QUAD_ROWS + t * RQ_TILE_ROWS + 4 * kg;
-            float m = binmax[t / R];
+            float m1 = binmax[t / R], m2 = bin2[t / R];
+            int ag = binarg[t / R];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float sc = acc[i] * nv[i];
                 sc = (row0 + i < a.n_rows) ? sc : NEG_INF;
-                m = fmaxf(m, sc);   // fmaxf drops NaN
+                const bool gt = sc > m1;                 // false for NaN: NaN scores are dropped
+                m2 = gt ? m1 : fmaxf(m2, sc);            // a tie with m1 makes m2 == m1 (both rows then count as >= m1)
+                ag = gt ? (t % R) * 4 + i : ag;
+                m1 = gt ? sc : m1;
             }
-            binmax[t / R] = m;
+            binmax[t / R] = m1; bin2[t / R] = m2; binarg[t / R] = ag;
         }
 #pragma unroll
         for (int u = 0; u < 4 / R; ++u) wmax = fmaxf(wmax, binmax[u]);
         if (16 * wave + r16 < a.nq_valid) {
-            float* dst = a.pooled + (int64_t)(16 * wave + r16) * a.pooled_stride + quad * (16 / R) + kg * (4 / R);
+            const int64_t off = (int64_t)(16 * wave + r16) * a.pooled_stride + quad * (16 / R) + kg * (4 / R);
+            float* dst = a.pooled + off;
+            // aux word per bin: [31:16] second-largest score rounded UP to 16 bits (an upper bound), [3:0] arg-max position
+            uint32_t ax[4 / R];
+#pragma unroll
+            for (int u = 0; u < 4 / R; ++u) ax[u] = rq_up16(bin2[u]) | (uint32_t)binarg[u];
+            uint32_t* adst = a.aux + off;
             if constexpr (R == 4) {
                 dst[0] = binmax[0];
+                adst[0] = ax[0];
             } else if constexpr (R == 2) {
                 *(float2*)dst = make_float2(binmax[0], binmax[1]);
+                *(uint2*)adst = make_uint2(ax[0], ax[1]);
             } else {
                 *(float4*)dst = make_float4(binmax[0], binmax[1], binmax[2], binmax[3]);
+                *(uint4*)adst = make_uint4(ax[0], ax[1], ax[2], ax[3]);
             }
         }
     }

@@ -7,7 +7,6 @@
 // order = (fp32 score desc, row asc).
 #include "rq_device.h"
 #include "rq_kernels.h"
-#include "rq_final_body.h"
 
 // --------------------------------------------------------------------------------------------
 // small helpers
@@ -122,8 +121,7 @@ hipError_t rq_pad_f16_launch(const void* src, int dim, int64_t n, void* dst, hip
 // --------------------------------------------------------------------------------------------
 // query preparation: one wave-sized pass per query (block = 256 threads, thread t owns 3 elements)
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rq_prep_queries_kernel(const float* q, int dim, int B, _Float16* qh, float* q32pad, double* qnorm64,
-                                                              int* bincount) {
+__global__ __launch_bounds__(256) void rq_prep_queries_kernel(const float* q, int dim, int B, _Float16* qh, float* q32pad, double* qnorm64) {
     __shared__ double part[4];
     const int qi = blockIdx.x, tid = threadIdx.x;
     float v[3];
@@ -138,7 +136,7 @@ __global__ __launch_bounds__(256) void rq_prep_queries_kernel(const float* q, in
     if ((tid & 63) == 0) part[tid >> 6] = acc;
     __syncthreads();
     const double nrm = sqrt((part[0] + part[1]) + (part[2] + part[3]));
-    if (tid == 0 && qi < B) { qnorm64[qi] = nrm; if (bincount) bincount[qi] = 0; }
+    if (tid == 0 && qi < B) qnorm64[qi] = nrm;
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
         const int i = p * 256 + tid;
@@ -148,8 +146,8 @@ __global__ __launch_bounds__(256) void rq_prep_queries_kernel(const float* q, in
     }
 }
 hipError_t rq_prep_queries_launch(const float* q, int dim, int B, int Bpad, _Float16* qh, float* q32pad, double* qnorm64,
-                                  int* bincount, hipStream_t stream) {
-    hipLaunchKernelGGL(rq_prep_queries_kernel, dim3(Bpad), dim3(256), 0, stream, q, dim, B, qh, q32pad, qnorm64, bincount);
+                                  hipStream_t stream) {
+    hipLaunchKernelGGL(rq_prep_queries_kernel, dim3(Bpad), dim3(256), 0, stream, q, dim, B, qh, q32pad, qnorm64);
     return hipGetLastError();
 }
 
@@ -362,163 +360,3 @@ hipError_t rq_merge_keys_launch(const uint64_t* keys, int n_per_query, int B, in
     return hipGetLastError();
 }
 
-// =============================================================================================
-// Fast tail (the common case: <= 128 bins wanted, k <= 128).  No sorting of bins at all:
-//   threshold T = m-th largest per-workgroup maximum written by the scan kernel.  At least m bins
-//   reach T (one per workgroup counted), so every bin with pooled >= T is a candidate and every
-//   other bin is bounded by T -- which is all the certificate needs.
-// =============================================================================================
-template <int NV4>
-__global__ __launch_bounds__(256) void rq_collect_kernel(RqCollectArgs a) {
-    __shared__ float thr_s;
-    const int q = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float NEG_INF = -__builtin_huge_valf();
-    const float* p = a.pooled + (int64_t)q * a.pooled_stride;
-    const int64_t cbase = (int64_t)blockIdx.x * (1024 * NV4) + tid * 4;
-    float4 v4[NV4];
-#pragma unroll
-    for (int u = 0; u < NV4; ++u) {
-        const int64_t i = cbase + (int64_t)u * 1024;   // pooled_stride is a multiple of 64: in-bounds up to the stride
-        v4[u] = (i < a.pooled_stride) ? *(const float4*)(p + i) : make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
-    }
-    // threshold: ballot radix select (wave 0) of the m-th largest partition maximum, top 20 key bits
-    if (wave == 0) {
-        const float* w = a.wgmax + (int64_t)q * a.wgmax_stride;
-        uint32_t prefix = 0;
-        if (a.m <= 24) {
-            float v = NEG_INF;
-            for (int j = lane; j < a.nwg; j += 64) v = fmaxf(v, w[j]);
-            const uint32_t key = rq_mono32(v);
-            for (int bit = 31; bit >= 12; --bit) {
-                const uint32_t t = prefix | (1u << bit);
-                if (__popcll(__ballot(key >= t)) >= a.m) prefix = t;
-            }
-        } else if (a.m <= 256) {
-            uint32_t key[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float v = NEG_INF;
-                for (int j = i * 64 + lane; j < a.nwg; j += 256) v = fmaxf(v, w[j]);
-                key[i] = rq_mono32(v);
-            }
-            for (int bit = 31; bit >= 12; --bit) {
-                const uint32_t t = prefix | (1u << bit);
-                int c = 0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) c += __popcll(__ballot(key[i] >= t));
-                if (c >= a.m) prefix = t;
-            }
-        }
-        if (lane == 0) thr_s = prefix > rq_mono32(NEG_INF) ? rq_unmono32(prefix) : NEG_INF;
-    }
-    __syncthreads();
-    const float T = thr_s;
-    if (blockIdx.x == 0 && tid == 0) a.thr[q] = T;
-#pragma unroll
-    for (int u = 0; u < NV4; ++u) {
-        const float xs[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int64_t i = cbase + (int64_t)u * 1024 + e;
-            if (i < a.nbins && xs[e] >= T) {
-                const int pos = atomicAdd(&a.bincount[q], 1);
-                if (pos < a.rmax) a.binlist[(int64_t)q * a.rmax + pos] = (int)i;
-            }
-        }
-    }
-}
-hipError_t rq_collect_launch(const RqCollectArgs& a, int B, hipStream_t stream) {
-    if (a.m < 1 || a.rmax < 1 || a.rmax > RQ_FAST_MAX_BINS) return hipErrorInvalidValue;
-    const int64_t wgs1 = ((a.nbins + 1023) / 1024) * B;
-    if (wgs1 <= 1536) {
-        const int64_t chunks = (a.nbins + 1023) / 1024;
-        if (chunks < 1 || chunks > 65535) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(rq_collect_kernel<1>, dim3((unsigned)chunks, B), dim3(256), 0, stream, a);
-    } else {
-        const int64_t chunks = (a.nbins + 4095) / 4096;
-        if (chunks < 1 || chunks > 65535) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(rq_collect_kernel<4>, dim3((unsigned)chunks, B), dim3(256), 0, stream, a);
-    }
-    return hipGetLastError();
-}
-
-// grid (rmax, B); 4 waves, wave w re-scores rows w*R .. w*R+R-1 of its bin, all loads issued up front.
-template <int R>
-__global__ __launch_bounds__(256) void rq_rescore_list_kernel(RqRescoreListArgs a) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q = blockIdx.y, slot = blockIdx.x;
-    int cnt = a.bincount[q];
-    cnt = cnt < a.rmax ? cnt : a.rmax;
-    if (slot >= cnt) return;
-    const int64_t bin = a.binlist[(int64_t)q * a.rmax + slot];
-    constexpr int binrows = 4 * R;
-    uint64_t* out = a.cand + ((int64_t)q * a.rmax + slot) * binrows;
-    const char* xb = (const char*)a.x;
-    rq_half4 xv[R][3];
-    int64_t rows[R];
-    double rn[R];
-#pragma unroll
-    for (int jj = 0; jj < R; ++jj) {
-        rows[jj] = rq_bin_row(bin, R, wave * R + jj);
-        const int64_t rr = rows[jj] < a.n_rows ? rows[jj] : 0;
-        rn[jj] = a.rownorm64[rr];
-        const char* r = xb + rr * (RQ_DPAD * 2);
-#pragma unroll
-        for (int p = 0; p < 3; ++p) xv[jj][p] = *(const rq_half4*)(r + p * 512 + lane * 8);
-    }
-    float qv[12];
-    const float* qp = a.q32 + (size_t)q * RQ_DPAD;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        const float4 t = *(const float4*)(qp + p * 256 + 4 * lane);
-        qv[p * 4 + 0] = t.x; qv[p * 4 + 1] = t.y; qv[p * 4 + 2] = t.z; qv[p * 4 + 3] = t.w;
-    }
-    const double qn = a.qnorm64[q];
-#pragma unroll
-    for (int jj = 0; jj < R; ++jj) {
-        double dot = 0.0;
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) dot += (double)qv[p * 4 + e] * (double)(float)xv[jj][p][e];
-        dot = rq_wave_sum(dot);
-        if (lane == 0) {
-            uint64_t key = 0;
-            if (rows[jj] < a.n_rows) {
-                double s = dot;
-                if (a.metric == 0) s = dot / (qn * rn[jj] + 1e-30);
-                key = rq_make_key(rq_sanitize((float)s), (uint32_t)rows[jj]);
-            }
-            out[wave * R + jj] = key;
-        }
-    }
-}
-hipError_t rq_rescore_list_launch(const RqRescoreListArgs& a, int B, hipStream_t stream) {
-    if (a.rmax < 1 || B < 1) return hipErrorInvalidValue;
-    const dim3 grid(a.rmax, B);
-    switch (a.R) {
-        case 4: hipLaunchKernelGGL(rq_rescore_list_kernel<4>, grid, dim3(256), 0, stream, a); break;
-        case 2: hipLaunchKernelGGL(rq_rescore_list_kernel<2>, grid, dim3(256), 0, stream, a); break;
-        case 1: hipLaunchKernelGGL(rq_rescore_list_kernel<1>, grid, dim3(256), 0, stream, a); break;
-        default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
-
-
-// One 256-thread workgroup per query; the selection itself is rq_final_body.h (shared with the fused tail).
-__global__ __launch_bounds__(256) void rq_final_fast_kernel(RqFinalFastArgs a) {
-    __shared__ RqFinalLds lds;
-    const int q = blockIdx.x;
-    RqFinalCore c;
-    c.cand = a.cand + (int64_t)q * a.rmax * a.binrows; c.rmax = a.rmax; c.binrows = a.binrows; c.metric = a.metric; c.eps = a.eps;
-    c.max_row_norm = a.max_row_norm; c.k = a.k; c.row_offset = a.row_offset; c.n_rows = a.n_rows;
-    c.out_scores = a.out_scores + (int64_t)q * a.k; c.out_rows = a.out_rows + (int64_t)q * a.k;
-    c.out_keys = a.out_keys ? a.out_keys + (int64_t)q * a.k : nullptr; c.out_status = a.out_status + q;
-    rq_final_body<false>(c, a.bincount[q], 0, a.thr[q], a.qnorm64[q], lds);
-}
-hipError_t rq_final_fast_launch(const RqFinalFastArgs& a, int B, hipStream_t stream) {
-    if (a.k < 1 || a.k > RQ_FAST_MAX_K || a.rmax * a.binrows > 4096) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(rq_final_fast_kernel, dim3(B), dim3(256), 0, stream, a);
-    return hipGetLastError();
-}

@@ -1,32 +1,37 @@
-// rq_tail.hip -- everything after the corpus scan in ONE launch (the common case: <= 128 bins, k <= 128).
+// rq_tail.hip -- everything after the corpus scan in ONE launch (the common case: <= 128 bins wanted, k <= 128).
 //
-// grid (chunks of 1024 bins, B queries), 256 threads.  Each workgroup
-//   A. derives the threshold T = m-th largest of 256 partition maxima (each the max of a few per-workgroup
-//      maxima written by the scan; valid because distinct scan workgroups own distinct bins, so at least m
-//      bins reach T) with a ballot radix select in wave 0, and the fp64 norm of its query,
-//   B. finds the bins of its chunk with pooled >= T (one float4 per thread),
-//   C. re-scores every row of those bins exactly in fp64: one wave per bin, 16 lanes per row, all loads of
-//      the bin's 4R rows in flight before the math, 4-step reductions; keys go to the query's candidate
-//      list with 8-byte write-through (sc1) stores,
-//   D. publishes: every wave drains vmcnt, workgroup barrier, ONE lane draws a ticket (agent-scope atomic
-//      add).  The workgroup that draws the last ticket of its query reads the keys with sc1 loads only,
-//      selects the exact top-k, evaluates the certificate and resets the counters.  No fences: a release
-//      fence per workgroup serialises on the L2 write-back (measured +60 us per launch).
+// grid (chunks of 1024*NV4 bins, B queries), 256 threads.  Each workgroup
+//   A. derives the threshold T = m-th largest partition maximum (partitions = groups of the scan's per-workgroup
+//      maxima; valid because distinct scan workgroups own distinct bins, so at least m bins reach T) with a
+//      20-bit ballot radix select in wave 0,
+//   B. finds the bins of its chunk with pooled >= T and turns them into ROW JOBS: the bin's arg-max row alone when
+//      the bin's second-largest approximate score (aux word, 16-bit upper bound) is below T -- the usual case --
+//      or all 4R rows of the bin otherwise,
+//   C. re-scores the job rows exactly in fp64 (16 lanes per row, 8 rows of loads in flight per wave) and appends the
+//      (score, row) keys to the query's compact candidate list with 8-byte write-through (sc1) stores,
+//   D. publishes: every wave drains vmcnt, workgroup barrier, ONE lane draws a ticket (agent-scope atomic add).  The
+//      workgroup that draws the last ticket of its query reads the keys with sc1 loads only, ranks them, writes the
+//      exact top-k and the certificate, and resets the counters.  No fences: a release fence per workgroup
+//      serialises on the L2 write-back (measured +60 us per launch).
+// Exactness: a row that is not re-scored has approximate score < T (it is either in a bin with pooled < T, or a
+// non-arg-max row of a bin whose second-largest score is < T), so its exact score is < T + eps; see rq_final_body.h.
 // Replaces reference rag_uq/streaming_index.py:355-368 (collection.query + `1 - distance`) after the scan.
 #include "rq_device.h"
 #include "rq_kernels.h"
 #include "rq_final_body.h"
 
-#define RQ_TAIL_LOCALCAP 64
+#define RQ_TAIL_HITCAP 64      // candidate bins one workgroup can hold
+#define RQ_TAIL_JOBCAP 512     // row jobs one workgroup can hold
 
 // NV4: float4 loads of pooled values per thread (chunk = 1024 * NV4 bins per workgroup)
 template <int R, int NV4>
-__global__ __launch_bounds__(256) void rq_tail_kernel(RqTailArgs a) {   // 168 VGPRs; capping at 128 spills and costs 30 % (measured)
+__global__ __launch_bounds__(256) void rq_tail_kernel(RqTailArgs a) {
     __shared__ __attribute__((aligned(16))) float qs[RQ_DPAD];   // the raw query, shared by the four waves
     __shared__ double qpart[4];
     __shared__ float thr_s;
-    __shared__ int nhit_s, base_s, last_s, total_s, ovf_s;
-    __shared__ int hits[RQ_TAIL_LOCALCAP];
+    __shared__ int nhit_s, njob_s, base_s, last_s, total_s, ovf_s;
+    __shared__ int hits[RQ_TAIL_HITCAP];
+    __shared__ int jobs[RQ_TAIL_JOBCAP];      // (hit << 4) | position of the row inside its bin
     __shared__ RqFinalLds flds;
     const int q = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float NEG_INF = -__builtin_huge_valf();
@@ -48,7 +53,7 @@ __global__ __launch_bounds__(256) void rq_tail_kernel(RqTailArgs a) {   // 168 V
 #pragma unroll
         for (int pp = 0; pp < 3; ++pp) { const int i = pp * 256 + tid; qmine[pp] = i < a.dim ? qp[i] : 0.f; qs[i] = qmine[pp]; }
     }
-    if (tid == 0) { thr_s = NEG_INF; nhit_s = 0; last_s = 0; }
+    if (tid == 0) { thr_s = NEG_INF; nhit_s = 0; njob_s = 0; last_s = 0; }
 
     // ---- A. threshold: ballot radix select (wave 0) of the m-th largest partition maximum, truncated to the
     //      top 20 key bits (a slightly lower, still valid threshold).  m <= 24: 64 partitions (one per lane),
@@ -87,27 +92,39 @@ __global__ __launch_bounds__(256) void rq_tail_kernel(RqTailArgs a) {   // 168 V
     const float T = thr_s;
     if (a.stop_after == 1) { if (tid == 0 && blockIdx.x == 0) a.out_status[q] = (int)T; return; }
 
-    // ---- B. bins of this chunk that reach the threshold
+    // ---- B. bins of this chunk that reach the threshold -> row jobs
+    {
+        const uint32_t* ax = a.aux + (int64_t)q * a.pooled_stride;
 #pragma unroll
-    for (int u = 0; u < NV4; ++u) {
-        const float xs[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
+        for (int u = 0; u < NV4; ++u) {
+            const float xs[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int64_t i = cbase + (int64_t)u * 1024 + e;
-            if (i < a.nbins && xs[e] >= T) {
-                const int h = atomicAdd(&nhit_s, 1);
-                if (h < RQ_TAIL_LOCALCAP) hits[h] = (int)i;
+            for (int e = 0; e < 4; ++e) {
+                const int64_t i = cbase + (int64_t)u * 1024 + e;
+                if (i < a.nbins && xs[e] >= T) {
+                    const int h = atomicAdd(&nhit_s, 1);
+                    if (h < RQ_TAIL_HITCAP) {
+                        hits[h] = (int)i;
+                        const uint32_t w = ax[i];
+                        const bool whole = rq_aux_second(w) >= T;          // a second row of the bin may reach T too
+                        const int nj = whole ? binrows : 1;
+                        const int j0 = atomicAdd(&njob_s, nj);
+                        for (int j = 0; j < nj; ++j)
+                            if (j0 + j < RQ_TAIL_JOBCAP) jobs[j0 + j] = (h << 4) | (whole ? j : (int)(w & 15u));
+                    }
+                }
             }
         }
     }
     __syncthreads();
     const int nh = nhit_s;
-    const int nloc = nh < RQ_TAIL_LOCALCAP ? nh : RQ_TAIL_LOCALCAP;
+    const int njob_all = njob_s;
+    const int njob = njob_all < RQ_TAIL_JOBCAP ? njob_all : RQ_TAIL_JOBCAP;
     if (tid == 0) {
-        base_s = nh ? atomicAdd(&a.bincount[q], nh) : 0;
-        if (nh > RQ_TAIL_LOCALCAP) atomicOr(&a.ovf[q], 1);
+        base_s = njob_all ? atomicAdd(&a.rowcount[q], njob_all) : 0;
+        if (nh > RQ_TAIL_HITCAP || njob_all > RQ_TAIL_JOBCAP) atomicOr(&a.ovf[q], 1);
     }
-    // fp64 norm of the query (only workgroups with hits, and later the last one, need it)
+    // fp64 norm of the query (only workgroups with jobs, and later the last one, need it)
     auto query_norm = [&]() -> double {
         double ssq = 0.0;
 #pragma unroll
@@ -125,26 +142,25 @@ __global__ __launch_bounds__(256) void rq_tail_kernel(RqTailArgs a) {   // 168 V
     else __syncthreads();
     if (a.stop_after == 2) return;
 
-    // ---- C. exact re-score.  Task = (hit, group of 4 rows); 16 lanes per row (sub = lane & 15 owns elements
-    //      pp*128 + 8*sub + e).  Every wave takes two tasks per round (8 rows of loads in flight), so a
-    //      workgroup clears 2 hits of 16 rows per round.
+    // ---- C. exact re-score of the job rows: 16 lanes per row (sub = lane & 15 owns elements pp*128 + 8*sub + e),
+    //      a wave takes 8 jobs per round (two groups of 4 rows, all 12 loads per lane in flight before the math)
     if (nh > 0 && qn != 0.0) {
         const int base = base_s;
         const int sub = lane & 15, rloc = lane >> 4;
         const char* xb = (const char*)a.x;
-        const int ntask = nloc * R;
-        for (int t0 = wave * 2; t0 < ntask; t0 += 8) {
+        uint64_t* out = a.cand + (int64_t)q * RQ_CAND_CAP;
+        for (int j0 = wave * 8; j0 < njob; j0 += 32) {
             rq_half8 xv[2][6];
             int64_t rows[2];
             double rn[2];
-            int slot[2], grp[2];
+            int pos[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int t = t0 + u < ntask ? t0 + u : t0;   // odd tail: repeat the first task, store is skipped
-                const int h = t / R;
-                grp[u] = t % R;
-                slot[u] = (t0 + u < ntask) ? base + h : a.rmax;   // slot >= rmax: nothing is stored
-                rows[u] = rq_bin_row((int64_t)hits[h], R, grp[u] * 4 + rloc);
+                const int jb = j0 + u * 4 + rloc;
+                const bool live = jb < njob;
+                const int job = jobs[live ? jb : 0];
+                pos[u] = (live && base + jb < RQ_CAND_CAP) ? base + jb : -1;   // -1: nothing stored (padding or list full)
+                rows[u] = rq_bin_row((int64_t)hits[job >> 4], R, job & 15);
                 const int64_t rr = rows[u] < a.n_rows ? rows[u] : 0;
                 rn[u] = a.rownorm64[rr];
                 const char* r = xb + rr * (RQ_DPAD * 2) + sub * 16;
@@ -166,16 +182,15 @@ __global__ __launch_bounds__(256) void rq_tail_kernel(RqTailArgs a) {   // 168 V
                 double d = dot[u];
 #pragma unroll
                 for (int off = 8; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
-                if (sub == 0 && slot[u] < a.rmax) {     // slot >= rmax: the last workgroup sees total > rmax = overflow
-                    uint64_t key = 0;
+                if (sub == 0 && pos[u] >= 0) {
+                    uint64_t key = 0;                                       // stays 0 for a row beyond the shard's end
                     if (rows[u] < a.n_rows) {
                         double sc = d;
                         if (a.metric == 0) sc = d / (qn * rn[u] + 1e-30);
                         key = rq_make_key(rq_sanitize((float)sc), (uint32_t)rows[u]);
                     }
                     // write-through (sc1) store: visible to the last workgroup without a release fence
-                    uint64_t* out = a.cand + ((int64_t)q * a.rmax + slot[u]) * binrows;
-                    __hip_atomic_store(&out[grp[u] * 4 + rloc], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&out[pos[u]], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
@@ -188,10 +203,10 @@ __global__ __launch_bounds__(256) void rq_tail_kernel(RqTailArgs a) {   // 168 V
     if (tid == 0) {
         const int ticket = __hip_atomic_fetch_add(&a.done[q], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (ticket == (int)gridDim.x - 1) {
-            total_s = __hip_atomic_load(&a.bincount[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            total_s = __hip_atomic_load(&a.rowcount[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ovf_s = __hip_atomic_load(&a.ovf[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // counters back to zero for the next launch on this workspace
-            __hip_atomic_store(&a.bincount[q], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.rowcount[q], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&a.ovf[q], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&a.done[q], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             last_s = 1;
@@ -202,11 +217,11 @@ __global__ __launch_bounds__(256) void rq_tail_kernel(RqTailArgs a) {   // 168 V
     if (qn < 0.0) qn = query_norm();   // uniform: this workgroup had no hits of its own
 
     RqFinalCore c;
-    c.cand = a.cand + (int64_t)q * a.rmax * binrows; c.rmax = a.rmax; c.binrows = binrows; c.metric = a.metric; c.eps = a.eps;
+    c.cand = a.cand + (int64_t)q * RQ_CAND_CAP; c.metric = a.metric; c.eps = a.eps;
     c.max_row_norm = a.max_row_norm; c.k = a.k; c.row_offset = a.row_offset; c.n_rows = a.n_rows;
     c.out_scores = a.out_scores + (int64_t)q * a.k; c.out_rows = a.out_rows + (int64_t)q * a.k;
     c.out_keys = a.out_keys ? a.out_keys + (int64_t)q * a.k : nullptr; c.out_status = a.out_status + q;
-    rq_final_body<true>(c, total_s, ovf_s, T, qn, flds);
+    rq_final_body(c, total_s, ovf_s, T, qn, flds);
 }
 
 template <int NV4>
@@ -224,8 +239,7 @@ static hipError_t rq_tail_launch_nv(const RqTailArgs& a, int B, hipStream_t stre
 }
 
 hipError_t rq_tail_launch(const RqTailArgs& a, int B, hipStream_t stream) {
-    if (a.m < 1 || a.rmax < 1 || a.rmax > RQ_FAST_MAX_BINS || a.k < 1 || a.k > RQ_FAST_MAX_K || a.rmax * 4 * a.R > 4096)
-        return hipErrorInvalidValue;
+    if (a.m < 1 || a.m > RQ_FAST_MAX_M || a.k < 1 || a.k > RQ_FAST_MAX_K) return hipErrorInvalidValue;
     // about a thousand workgroups: enough to spread the hits, few enough to be one dispatch round
     const int64_t wgs1 = ((a.nbins + 1023) / 1024) * B;
     return wgs1 <= 1536 ? rq_tail_launch_nv<1>(a, B, stream) : rq_tail_launch_nv<4>(a, B, stream);

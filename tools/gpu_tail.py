@@ -26,15 +26,15 @@ for N in (1_000_000, 125_000):
             t = idx.timing()
             print(f"N={N} k={k} tail_stop={stop}: tail {t['scan_ms']*1e3/max(t['scan_launches'],1):7.1f} us   e2e {dt*1e6:7.1f} us", flush=True)
         idx.set_option("tail_stop", 0)
-        for mode in (0, 1):
-            idx.set_option("fused_tail", mode); idx.set_option("profile", 0)
+        for mode in (1,):
+            idx.set_option("profile", 0)
             for i in range(6): idx.search_device(qs[i % 8], B, k, 0, o[0], o[1], o[2], o[3], 0)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(40): idx.search_device(qs[i % 8], B, k, 0, o[0], o[1], o[2], o[3], 0)
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 40
             print(f"N={N} k={k} tail mode {mode}: e2e {dt*1e6:7.1f} us (uncertified {int(o[3].sum())})", flush=True)
-        idx.set_option("fused_tail", 1); idx.set_option("profile", 1)
+        idx.set_option("profile", 1)
         for i in range(4): idx.search_device(qs[i % 8], B, k, 0, o[0], o[1], o[2], o[3], 0)
         torch.cuda.synchronize(); idx.reset_timing()
         for i in range(30): idx.search_device(qs[i % 8], B, k, 0, o[0], o[1], o[2], o[3], 0)
