@@ -234,8 +234,11 @@ def main() -> None:
                      "avg_launch_us": scan_us, "launches": timing["scan_launches"], "algorithmic_bytes_per_launch": algo_bytes,
                      "isolated": {"avg_launch_us": iso_us, "achieved": algo_bytes / (iso_us * 1e-6) / 1e9 if iso_us > 0 else 0.0,
                                   "frac": (algo_bytes / (iso_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if iso_us > 0 else 0.0,
-                                  "note": "same kernel, 24 launches on one stream after the timed region; the live figure above "
-                                          "is taken while two streams overlap, which stretches every launch"}},
+                                  "note": "same kernel, 24 launches on one stream right after the timed region.  The live figure "
+                                          "above brackets every launch with HIP events while two caller streams alternate: the "
+                                          "interval then starts when the launch is dequeued and includes the wait for the other "
+                                          "stream's scan to release its workgroup slots (rocprofv3 dispatch timestamps agree), so "
+                                          "it is queue wait + execution; the isolated figure is execution only"}},
         "repaired_queries": fixed,
         "exact_scans": timing["exact_scans"],
     }
