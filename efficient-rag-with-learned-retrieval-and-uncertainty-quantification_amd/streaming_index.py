@@ -234,7 +234,7 @@ class DenseIndex:
     def __init__(self, collection_name: str = "rag_documents", persist_directory: str = "./data/chroma_db",
                  embedding_model: str = "nomic-embed-text", chroma_host: Optional[str] = None, chroma_port: int = 8000,
                  *, embedder=None, device: int = 0, devices: Optional[Sequence[int]] = None, metric: str = "cosine",
-                 load_persisted: bool = True):
+                 load_persisted: bool = True, auto_persist: bool = True):
         self.collection_name = collection_name
         self.persist_directory = persist_directory
         self.embedding_model = embedding_model
@@ -246,6 +246,7 @@ class DenseIndex:
         self.device = int(device)
         self.devices = [int(d) for d in devices] if devices else None     # several GPUs in this process: rows are sharded
         self.metric = _native.METRIC_IP if metric in ("ip", "inner_product") else _native.METRIC_COSINE
+        self.auto_persist = bool(auto_persist) and bool(persist_directory)   # Chroma's PersistentClient is durable on add (:257)
         self.dim: Optional[int] = None
         self._index: Optional[_native.NativeIndex] = None
         self._ids: List[str] = []
@@ -327,12 +328,32 @@ class DenseIndex:
         self._ensure_index(vectors.shape[1])
         # cosine index: rows are unit-normalised before fp16 rounding (cosine is invariant, fp16 range is safe)
         self._index.add_f32(vectors, normalize=self.metric == _native.METRIC_COSINE)
+        first_new = len(self._ids)
         for j, doc_id in enumerate(ids):
             self._row_of[doc_id] = len(self._ids)
             self._ids.append(doc_id)
             self._texts.append(texts[j] if texts is not None else "")
             self._metas.append(dict(metadatas[j]) if metadatas is not None else {})
+        if self.auto_persist and hasattr(self._index, "get_rows_f16"):
+            self._persist_append(first_new)
         return len(ids)
+
+    def _persist_append(self, first_new: int) -> None:
+        """Append the rows [first_new, len) to the rq_save layout (<collection>.f16 / .meta) and their records to
+        <collection>.docs.jsonl, so that a later process finds the index (reference: Chroma persists on add)."""
+        docs_path, base = self._files()
+        docs_path.parent.mkdir(parents=True, exist_ok=True)
+        n = len(self._ids)
+        f16_path, meta_path = Path(str(base) + ".f16"), Path(str(base) + ".meta")
+        if first_new == 0 or not f16_path.exists():
+            first_new = 0                         # (re)write from scratch
+        rows = self._index.get_rows_f16(first_new, n - first_new)
+        with open(f16_path, "ab" if first_new else "wb") as f:
+            f.write(np.ascontiguousarray(rows).view(np.uint16).tobytes())
+        with open(docs_path, "a" if first_new else "w") as f:
+            for i in range(first_new, n):
+                f.write(json.dumps({"id": self._ids[i], "text": self._texts[i], "metadata": self._metas[i]}) + "\n")
+        meta_path.write_text(f"rq-index 1\ndim {self.dim}\nrows {n}\ndtype f16\n")
 
     # ---- query (reference :338-370) -------------------------------------------------------------------
     def search_vectors(self, vectors: np.ndarray, top_k: int = 10) -> List[List[Tuple[str, float, str]]]:
@@ -417,7 +438,10 @@ class HybridRetriever:
         else:
             self.dense_index = None
             logger.warning("Dense retrieval disabled")   # reference :418-420
-        self.documents: Dict[str, Document] = {}
+        # The reference starts with an empty document store (:422-423) although both indexes persist, so a fresh
+        # process over a persisted index answers [].  The BM25 pickle holds every Document:
+        # restore the store from it (same signatures, DESIGN.md "deviations").
+        self.documents: Dict[str, Document] = dict(self.bm25_index.documents)
 
     def add_documents(self, documents: List[Document], batch_size: int = 100) -> Dict[str, int]:
         for doc in documents:

@@ -230,10 +230,15 @@ def test_dense_index_and_hybrid_retriever_end_to_end(tmp_path):
     assert [len(v) for v in a] == [20, 20, 20, 20]
     b = r.get_scores_for_router_batch(["topic 5 item 9", "passage 3"], num_passages=20)
     assert b[0] == a
-    # persistence of the dense side, then a fresh process-like reload
-    r.dense_index.save()
+    # the dense side persisted itself on every add (like Chroma's PersistentClient): a fresh process-like reload
     again = si.DenseIndex(persist_directory=str(tmp_path / "chroma"), embedder=HashEmbedder())
     assert len(again) == 500 and again.search(docs[42].text, 1)[0][0] == "p42"
+    assert again.search("passage 3 about topic 3", 20) == r.dense_index.search("passage 3 about topic 3", 20)
+    again.add_documents([si.Document(id="late", text="a late passage about nothing")])          # appends to the files
+    third = si.DenseIndex(persist_directory=str(tmp_path / "chroma"), embedder=HashEmbedder())
+    assert len(third) == 501 and third.search("a late passage about nothing", 1)[0][0] == "late"
+    fresh = si.HybridRetriever(bm25_persist_path=str(tmp_path / "b.pkl"), chroma_persist_path=str(tmp_path / "chroma"), embedder=HashEmbedder())
+    assert len(fresh) == 500 and fresh.hybrid_search(docs[42].text, top_k=1)[0].doc_id == "p42"
     # failed embedding -> zero vector -> still answers (reference :281-284)
     class Broken:
         dim = 32

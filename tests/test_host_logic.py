@@ -119,7 +119,7 @@ def test_streaming_index_checkpoint_and_resume(tmp_path):
     assert list(s2.stream_from_jsonl(str(path))) == [3, 1]
     ck = json.load(open(tmp_path / "ck.json"))
     assert ck == {"last_offset": 9, "total_indexed": 7, "files_completed": [str(path)]}
-    assert s2.get_progress()["retriever_size"] == 4
+    assert s2.get_progress()["retriever_size"] == 7    # 3 restored from the BM25 pickle + 4 new (the reference would say 4)
     assert len(r2.bm25_index) == 7                     # BM25 pickle carried the first three over
     with pytest.raises(FileNotFoundError):
         list(s2.stream_from_jsonl(str(tmp_path / "missing.jsonl")))
@@ -146,3 +146,15 @@ def test_callable_embedder_shape_check():
     assert e.embed(["a", "b"]).shape == (2, 5)
     with pytest.raises(ValueError):
         CallableEmbedder(lambda ts: np.ones((1, 5)), 5).embed(["a", "b"])
+
+
+def test_document_store_is_restored_from_bm25_pickle(tmp_path):
+    """a second process over the same persist paths can answer hybrid queries (the reference returns [] there)"""
+    docs = [si.Document(id=i, text=t, title=f"T{i}") for i, t in CORPUS]
+    r1 = si.HybridRetriever(bm25_persist_path=str(tmp_path / "b.pkl"), chroma_persist_path=str(tmp_path / "c"), dense_index=None)
+    r1.dense_index = None
+    r1.add_documents(docs)
+    r2 = si.HybridRetriever(bm25_persist_path=str(tmp_path / "b.pkl"), chroma_persist_path=str(tmp_path / "c"), dense_index=None)
+    r2.dense_index = None
+    assert len(r2) == len(docs) and r2.documents["d3"].title == "Td3"
+    assert [x.doc_id for x in r2.hybrid_search("blue whales", top_k=2)] == [x.doc_id for x in r1.hybrid_search("blue whales", top_k=2)]
