@@ -47,7 +47,7 @@ struct Workspace {
     int bcap = 0;                 // query slots (multiple of 64)
     int64_t pooled_stride = 0;    // floats per query
     int64_t binkeys_cap = 0;      // entries per query
-    int64_t cand_cap = 0;         // entries per query
+    size_t cand_elems = 0;        // candidate keys allocated in total (queries of a call x keys per query)
     _Float16* qh = nullptr;
     float* q32 = nullptr;
     double* qn = nullptr;
@@ -364,7 +364,7 @@ static int ensure(T*& p, size_t want_elems) {
     return RQ_OK;
 }
 
-static int ensure_ws(Workspace& w, int bpad, int64_t stride, int64_t m, int64_t ncand) {
+static int ensure_ws(Workspace& w, int bpad, int64_t stride, int64_t m, size_t cand_elems) {
     const bool regrow_b = bpad > w.bcap;
     const int bcap = std::max(bpad, w.bcap);
     if (regrow_b) {
@@ -389,10 +389,9 @@ static int ensure_ws(Workspace& w, int bpad, int64_t stride, int64_t m, int64_t 
         if (int r = ensure(w.binkeys, (size_t)bcap * mm)) return r;
         w.binkeys_cap = mm;
     }
-    if (regrow_b || ncand > w.cand_cap) {
-        const int64_t nc = std::max(ncand, w.cand_cap);
-        if (int r = ensure(w.cand, (size_t)bcap * nc)) return r;
-        w.cand_cap = nc;
+    if (cand_elems > w.cand_elems) {   // sized by the queries of the call, not by the padded slot count: an exact scan of
+        if (int r = ensure(w.cand, cand_elems)) return r;   // one query holds a key for every row of the shard
+        w.cand_elems = cand_elems;
     }
     w.bcap = bcap;
     return RQ_OK;
@@ -465,7 +464,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
         if (int r = flush_tails(idx, s)) return r;   // order after anything still on the tail stream
     }
     Workspace& w = cx.w[par];
-    if (int r = ensure_ws(w, bpad, exact ? 64 : stride, exact ? 1 : m, ncand)) return r;
+    if (int r = ensure_ws(w, bpad, exact ? 64 : stride, exact ? 1 : m, (size_t)B * (size_t)ncand)) return r;
     const float* scale = idx->inv_norm;
     if (metric == RQ_METRIC_IP) { if (int r = ensure_ones(idx, s)) return r; scale = idx->ones; }
 
