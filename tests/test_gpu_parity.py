@@ -495,3 +495,33 @@ def test_scan_bin_maxima_within_certificate_eps(bin_tiles):
     assert worst <= 7e-4, worst
     assert worst <= 1e-4, f"observed error {worst} is far above the ~1e-5 expected from fp16 query rounding"
     idx.close()
+
+
+def test_device_pointer_append_paths_match_host_paths():
+    import torch
+    dev = torch.device("cuda:0")
+    x32 = np.random.default_rng(71).standard_normal((2_000, 300)).astype(np.float32) * 5
+    host = nat.NativeIndex(300, 0); host.add_f32(x32, True)
+    devi = nat.NativeIndex(300, 0)
+    t = torch.from_numpy(x32).to(dev)
+    devi.add_f32_device(t * 1.0, 2_000, True)          # rows produced by a kernel on torch's stream just before the call
+    assert np.array_equal(devi.get_rows_f16(0, 2_000).view(np.uint16), host.get_rows_f16(0, 2_000).view(np.uint16))
+    h16 = host.get_rows_f16(0, 2_000)
+    dev16 = nat.NativeIndex(300, 0)
+    dev16.add_f16_device(torch.from_numpy(h16.view(np.int16)).to(dev), 2_000)
+    assert np.array_equal(dev16.get_rows_f16(0, 2_000).view(np.uint16), h16.view(np.uint16))
+    _check(dev16, h16, orc.synthetic_queries(5, 300, 72), 7)
+    for i in (host, devi, dev16):
+        i.close()
+
+
+def test_large_batch_uses_wide_pass_and_stays_exact():
+    x16 = orc.synthetic_corpus(20_000, 768, seed=81)
+    idx = nat.NativeIndex(768, 0)
+    idx.add_f16(x16)
+    q = orc.synthetic_queries(1_000, 768, seed=82)          # 1000 queries: 7 passes of 128 + 1 partial
+    s, r = _check(idx, x16, q, 10)
+    idx.set_option("wide_batch", 0)
+    s2, r2 = idx.search(q, 10)
+    assert np.array_equal(r, r2) and np.array_equal(s, s2)
+    idx.close()
