@@ -525,3 +525,25 @@ def test_large_batch_uses_wide_pass_and_stays_exact():
     s2, r2 = idx.search(q, 10)
     assert np.array_equal(r, r2) and np.array_equal(s, s2)
     idx.close()
+
+
+def test_baseline_config0_10k_passages_100_queries_top10(tmp_path):
+    """BASELINE.json configs[0]: 10k-passage x 768-d synthetic corpus (seed 1234), 100 queries (seed 4321), cosine
+    top-10 -- the oracle is the 'CPU brute force via the streaming_index API'; the GPU path goes through the
+    reference-shaped DenseIndex (ids are strings, scores Python floats), one query per call AND batched."""
+    from rag_uq_amd import streaming_index as si
+    rng = np.random.default_rng(1234)
+    x32 = rng.standard_normal((10_000, 768)).astype(np.float32)
+    q = orc.synthetic_queries(100, 768, seed=4321)
+    x16 = orc.prepare_rows_f32(x32, True)
+    gs, gr = orc.dense_topk(q, x16, 10)
+    idx = si.DenseIndex(persist_directory=str(tmp_path / "c0"), embedder=None, load_persisted=False, auto_persist=False)
+    idx.add_vectors([f"d{i}" for i in range(10_000)], x32, texts=[f"passage {i}" for i in range(10_000)])
+    batched = idx.search_vectors(q, top_k=10)
+    for b in range(100):
+        assert [d for d, _, _ in batched[b]] == [f"d{i}" for i in gr[b]]
+        np.testing.assert_allclose([s for _, s, _ in batched[b]], gs[b], atol=SCORE_TOL)
+    for b in (0, 17, 99):                                   # the reference's call pattern: one query per call (:355-356)
+        single = idx.search_vectors(q[b], top_k=10)[0]
+        assert single == batched[b]
+    assert orc.recall_at_k(np.array([[int(d[1:]) for d, _, _ in r] for r in batched]), gr) == 1.0
