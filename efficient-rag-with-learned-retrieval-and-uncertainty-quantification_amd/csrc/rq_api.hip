@@ -81,6 +81,9 @@ struct StreamCtx {
     uint64_t calls = 0;
 };
 
+// Default scan variant: whole-row stages (kstage 1), ring of 2, one LDS fragment ahead (prefetch 1, <= 168 VGPRs),
+// 2 workgroups per CU.  All variants stream at the same 6.2 TB/s; this one leaves room on every SIMD
+// (2 x 168 + 168 <= 512 VGPRs) for a tail workgroup of another stream to be resident beside the scan.
 struct rq_index {
     int dim = 0, device = 0, cu_count = 256;
     int64_t n = 0, cap = 0, row_offset = 0;
@@ -92,7 +95,7 @@ struct rq_index {
     double* d_maxnorm = nullptr;   // device scalar, bits of the running max row norm
     double max_row_norm = 0.0;
     // options
-    int ring = 4, prefetch = 4, kstage = 2, wide_batch = 1, bin_tiles = 4, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, fast_tail = 1, pipeline = 0, tail_stop = 0;
+    int ring = 2, prefetch = 1, kstage = 1, wide_batch = 1, bin_tiles = 4, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, fast_tail = 1, pipeline = 0, tail_stop = 0;
     double eps = -1.0;
     std::map<hipStream_t, StreamCtx> ctx;
     hipStream_t own_stream = nullptr;

@@ -97,7 +97,9 @@ int rq_search_fixup_device(rq_index* idx, const float* d_queries, int B, int k, 
 int rq_merge_keys_device(const uint64_t* d_keys_in, int n_per_query, int B, int k, float* d_scores, int64_t* d_rows,
                          uint64_t* d_keys_out, void* stream);
 
-/* Tuning / test hooks: "ring" (LDS stages 3..6), "bin_tiles" (1,2,4: bin = 4*bin_tiles rows),
+/* Tuning / test hooks: "kstage" (1: an LDS stage holds whole rows, 2: half rows), "ring" (LDS stages 2..6; the
+ * (kstage, ring, prefetch) triples built are listed in csrc/rq_scan.hip, others fail with RQ_EHIP at search time),
+ * "bin_tiles" (1,2,4: bin = 4*bin_tiles rows),
  * "wg_per_cu", "nt" (non-temporal corpus loads: 0, 1, -1 = auto), "slack_bins" (extra bins beyond k, -1 = auto),
  * "eps" (certificate bound, <0 = derived default), "profile" (record HIP events around every scan launch),
  * "prefetch" (LDS fragments read ahead of their MFMAs: 1, 4, 6, 12), "fast_tail" (0 = generic sorted tail),

@@ -107,13 +107,13 @@ def run(tag, iters=40, nstreams=1, k=10):
     res.append(dict(tag=tag, scan_us=scan_us, gbs=gbs, e2e_us=dt * 1e6, qps=B / dt, uncertified=bad))
 
 for ring, pf, wg in [(4, 1, 3), (4, 4, 2), (6, 12, 2), (5, 6, 2)]:
-    idx.set_option("ring", ring); idx.set_option("prefetch", pf); idx.set_option("wg_per_cu", wg); idx.set_option("nt", 1)
+    idx.set_option("kstage", 2); idx.set_option("ring", ring); idx.set_option("prefetch", pf); idx.set_option("wg_per_cu", wg); idx.set_option("nt", 1)
     for ns, pipe in ((1, 0), (2, 0), (1, 1), (2, 1)):
         idx.set_option("pipeline", pipe)
         run(f"ring={ring} pf={pf} wg/cu={wg} streams={ns} pipeline={pipe} k=10", nstreams=ns)
         for st_ in streams: idx.search_flush_device(st_.cuda_stream)
         torch.cuda.synchronize()
-idx.set_option("ring", 4); idx.set_option("prefetch", 4); idx.set_option("wg_per_cu", 2); idx.set_option("pipeline", 1)
+idx.set_option("kstage", 1); idx.set_option("ring", 2); idx.set_option("prefetch", 1); idx.set_option("wg_per_cu", 2); idx.set_option("pipeline", 1)
 for kk in (1, 50, 100):
     run(f"default pipeline streams=1 k={kk}", nstreams=1, k=kk)
 for st_ in streams: idx.search_flush_device(st_.cuda_stream)

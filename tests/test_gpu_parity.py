@@ -136,9 +136,13 @@ def test_clustered_near_ties():
     idx.close()
 
 
-@pytest.mark.parametrize("opts", [dict(fast_tail=0), dict(fast_tail=0, bin_tiles=1), dict(pipeline=1), dict(bin_tiles=2), dict(wide_batch=0), dict(kstage=1, ring=2), dict(bin_tiles=1), dict(ring=3, prefetch=1),
-                                  dict(ring=6, prefetch=12, wg_per_cu=2), dict(ring=5, prefetch=6, wg_per_cu=2, nt=0),
-                                  dict(wg_per_cu=1), dict(slack_bins=0)])
+@pytest.mark.parametrize("opts", [dict(fast_tail=0), dict(fast_tail=0, bin_tiles=1), dict(pipeline=1), dict(bin_tiles=2), dict(wide_batch=0),
+                                  dict(bin_tiles=1), dict(wg_per_cu=1), dict(slack_bins=0),
+                                  # every scan instantiation built in csrc/rq_scan.hip: (kstage, ring, prefetch)
+                                  dict(kstage=1, ring=2, prefetch=1), dict(kstage=1, ring=2, prefetch=4), dict(kstage=1, ring=3, prefetch=4),
+                                  dict(kstage=1, ring=3, prefetch=12), dict(kstage=1, ring=4, prefetch=4),
+                                  dict(kstage=2, ring=3, prefetch=1), dict(kstage=2, ring=4, prefetch=1), dict(kstage=2, ring=4, prefetch=4),
+                                  dict(kstage=2, ring=6, prefetch=4), dict(kstage=2, ring=5, prefetch=6, nt=0), dict(kstage=2, ring=6, prefetch=12)])
 def test_every_kernel_variant_is_exact(corpus100k, opts):
     _, x16 = corpus100k
     idx = nat.NativeIndex(768, 0)
