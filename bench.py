@@ -44,8 +44,9 @@ def main() -> None:
     ap.add_argument("--rows", type=int, default=N_ROWS)
     ap.add_argument("--k", type=int, default=TOPK)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=2, help="caller streams the batches alternate over")
-    ap.add_argument("--pipeline", type=int, default=0, help="1: tail kernels on the library's internal stream")
+    ap.add_argument("--streams", type=int, default=0, help="caller streams the batches alternate over (0 = 1 at one GPU, 2 at several)")
+    ap.add_argument("--event-stride", type=int, default=4, help="HIP events around every n-th scan launch of the timed region")
+    ap.add_argument("--pipeline", type=int, default=2, help="deferred tails: 1 = on the library's internal stream, 2 = fused into the next scan launch")
     args = ap.parse_args()
 
     import numpy as np
@@ -83,6 +84,12 @@ def main() -> None:
     idx.reserve(max(n_local, 1))
     idx.set_row_offset(row_lo)
     idx.set_option("pipeline", args.pipeline)
+    # One GPU: one caller stream, so scan launches never overlap each other and the per-launch HIP events (and
+    # rocprofv3) read the kernel's own duration; the tail of batch i hides inside the scan launch of batch i+1
+    # (pipeline 2).  Several GPUs (125k-row shards, ~35 us steps): two caller streams also hide the query prep
+    # and the launch gaps (measured 34.8 vs 50.1 us per step); per-launch events are off there.
+    if args.streams <= 0:
+        args.streams = 2 if use_comm else 1
     for c in range(c_lo, c_hi):
         g = torch.Generator(device=dev)
         g.manual_seed(1235 + c)
@@ -112,11 +119,12 @@ def main() -> None:
 
     def flush():
         """all-gather the local keys of the pending batches (one RCCL call) and merge them on the GPU"""
+        for s in streams:
+            idx.search_flush_device(s.cuda_stream)      # deferred tails of earlier searches run / become ordered on s
         if not use_comm or pending["n"] == 0:
             return
         r = pending["ring"]
         for s in streams:
-            idx.search_flush_device(s.cuda_stream)      # tails of earlier searches become ordered on s
             comm_stream.wait_stream(s)
         with torch.cuda.stream(comm_stream):
             dist.all_gather_into_tensor(gathered[r], ring[r])
@@ -178,6 +186,7 @@ def main() -> None:
     # them and the roofline comes from the calibration launches after it.
     live_events = not use_comm or os.environ.get("RQ_BENCH_LIVE_EVENTS") == "1"
     idx.set_option("profile", 1 if live_events else 0)
+    idx.set_option("profile_stride", max(1, args.event_stride))
     idx.reset_timing()
     sync_all()
     t0 = time.perf_counter()
@@ -195,12 +204,15 @@ def main() -> None:
     timing = idx.timing()
     # calibration outside the timed region: the same launches on ONE stream (no overlap with a second scan), so the
     # stand-alone duration of the kernel can be read next to the live one
+    idx.set_option("pipeline", 0)             # plain scan kernel, tail after it: the scan's stand-alone duration
     idx.set_option("profile", 1)
+    idx.set_option("profile_stride", 1)
     idx.reset_timing()
     for i in range(24):
         o = slots[i % N_QUERY_BATCHES]
         idx.search_device(queries[i % N_QUERY_BATCHES], B, k, nat.METRIC_COSINE, o["scores"], o["rows"], o["keys"], o["status"],
                           streams[0].cuda_stream)
+    idx.search_flush_device(streams[0].cuda_stream)
     torch.cuda.synchronize()
     iso = idx.timing()
     iso_us = iso["scan_ms"] * 1e3 / max(iso["scan_launches"], 1)
@@ -237,17 +249,17 @@ def main() -> None:
                    "rows_per_gpu": n_local, "streams": len(streams), "pipeline": args.pipeline, "gather_every": GATHER_EVERY if use_comm else 0,
                    "parallelism": f"row-shard x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "rq_scan_kernel",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "rq_scan_tail_kernel" if args.pipeline == 2 else "rq_scan_kernel",
                      "avg_launch_us": scan_us, "launches": timing["scan_launches"], "algorithmic_bytes_per_launch": algo_bytes,
-                     "measured": "HIP events around every scan launch of the timed region" if live_events else
+                     "measured": f"HIP events around every {max(1, args.event_stride)}-th scan launch of the timed region, on the stream it is launched on" if live_events else
                                  "HIP events around 24 single-stream launches right after the timed region (N > 1: no events inside it)",
                      "isolated": {"avg_launch_us": iso_us, "achieved": algo_bytes / (iso_us * 1e-6) / 1e9 if iso_us > 0 else 0.0,
                                   "frac": (algo_bytes / (iso_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if iso_us > 0 else 0.0,
-                                  "note": "same kernel, 24 launches on one stream right after the timed region.  The live figure "
-                                          "above brackets every launch with HIP events while two caller streams alternate: the "
-                                          "interval then starts when the launch is dequeued and includes the wait for the other "
-                                          "stream's scan to release its workgroup slots (rocprofv3 dispatch timestamps agree), so "
-                                          "it is queue wait + execution; the isolated figure is execution only"}},
+                                  "note": "rq_scan_kernel alone (pipeline 0), 24 launches on one stream right after the timed region.  With one "
+                                          "caller stream (the N = 1 default) the live figure is the same scan with the previous batch's "
+                                          "tail workgroups riding along; with two caller streams "
+                                          "a live interval would start when the launch is dequeued and include the wait for the "
+                                          "other stream's scan to release its workgroup slots (queue wait + execution)"}},
         "repaired_queries": fixed,
         "exact_scans": timing["exact_scans"],
     }

@@ -79,6 +79,10 @@ struct StreamCtx {
     hipEvent_t ev_tail[2] = {nullptr, nullptr};
     bool tail_pending[2] = {false, false};
     uint64_t calls = 0;
+    // "pipeline" = 2: the tail of the last search waits here and rides along with the next scan launch of the stream
+    bool fused_pending = false;
+    RqTailArgs fused_tail;
+    int fused_B = 0;
 };
 
 // Default scan variant: whole-row stages (kstage 1), ring of 2, one LDS fragment ahead (prefetch 1, <= 168 VGPRs),
@@ -94,8 +98,9 @@ struct rq_index {
     int64_t ones_valid = 0;
     double* d_maxnorm = nullptr;   // device scalar, bits of the running max row norm
     double max_row_norm = 0.0;
+    uint64_t scan_seq = 0;         // scan launches seen while profile = 1 (every profile_stride-th one is timed)
     // options
-    int ring = 2, prefetch = 1, kstage = 1, wide_batch = 1, bin_tiles = 4, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, fast_tail = 1, pipeline = 0, tail_stop = 0;
+    int ring = 2, prefetch = 1, kstage = 1, wide_batch = 1, bin_tiles = 4, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, profile_stride = 1, fast_tail = 1, pipeline = 0, tail_stop = 0;
     double eps = -1.0;
     std::map<hipStream_t, StreamCtx> ctx;
     hipStream_t own_stream = nullptr;
@@ -136,12 +141,15 @@ extern "C" int rq_device_count(void) {
 extern "C" const char* rq_last_error(void) { return g_err; }
 extern "C" const char* rq_version(void) { return "rq-hip 0.1 (gfx950)"; }
 
+static int flush_all(rq_index* idx);   // launches every tail still waiting for a scan ("pipeline" = 2)
+
 static int grow(rq_index* idx, int64_t want_rows) {
     if (want_rows <= idx->cap) return RQ_OK;
     int64_t cap = std::max<int64_t>(idx->cap * 2, 4096);
     while (cap < want_rows) cap *= 2;
     if (want_rows > (int64_t)1 << 27 && cap > want_rows + want_rows / 8) cap = want_rows + want_rows / 8;   // big shards: 12% headroom
     cap = (cap + 63) / 64 * 64;
+    if (int r = flush_all(idx)) return r;
     HIPCHK(hipDeviceSynchronize());   // searches in flight on any stream still read the old buffers
     char* nx = nullptr; double* nn = nullptr; float* ni = nullptr;
     hipError_t e = hipMalloc((void**)&nx, (size_t)cap * RQ_DPAD * 2);
@@ -268,6 +276,7 @@ static int add_device_common(rq_index* idx, const void* d_rows, int64_t n_rows, 
     // The rows may have been produced on any stream of the caller (e.g. torch's): wait for all of it.
     // Appending is not a hot path; searches in flight on other streams are drained too, which also
     // makes it safe to reallocate the shard below.
+    if (int r = flush_all(idx)) return r;
     HIPCHK(hipDeviceSynchronize());
     if (int r = grow(idx, idx->n + n_rows)) return r;
     char* dst = idx->x + (size_t)idx->n * RQ_DPAD * 2;
@@ -329,8 +338,9 @@ extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     else if (s == "slack_bins") idx->slack_bins = (int)v;
     else if (s == "eps") idx->eps = v;
     else if (s == "profile") idx->profile = (int)v;
+    else if (s == "profile_stride") { if (v < 1) return set_err(RQ_EINVAL, "profile_stride must be >= 1"); idx->profile_stride = (int)v; }
     else if (s == "fast_tail") idx->fast_tail = (int)v;
-    else if (s == "pipeline") idx->pipeline = (int)v;
+    else if (s == "pipeline") { if (v != 0 && v != 1 && v != 2) return set_err(RQ_EINVAL, "pipeline must be 0, 1 or 2"); if (int r = flush_all(idx)) return r; idx->pipeline = (int)v; }
     else if (s == "tail_stop") idx->tail_stop = (int)v;
     else return set_err(RQ_EINVAL, "unknown option '%s'", name);
     return RQ_OK;
@@ -350,6 +360,7 @@ extern "C" double rq_get_option(const rq_index* idx, const char* name) {
     if (s == "profile") return idx->profile;
     if (s == "fast_tail") return idx->fast_tail;
     if (s == "pipeline") return idx->pipeline;
+    if (s == "profile_stride") return idx->profile_stride;
     if (s == "cu_count") return idx->cu_count;
     if (s == "max_row_norm") return idx->max_row_norm;
     return NAN;
@@ -418,11 +429,16 @@ static int fill_empty(int B, int k, float* d_scores, int64_t* d_rows, uint64_t* 
     return RQ_OK;
 }
 
-// Make `s` wait for every tail still running on the internal tail stream of `s` (pipeline mode).
+// Make `s` wait for every tail still running on the internal tail stream of `s` (pipeline = 1) and launch the
+// tail that was waiting for the next scan (pipeline = 2).
 static int flush_tails(rq_index* idx, hipStream_t s) {
     auto it = idx->ctx.find(s);
     if (it == idx->ctx.end()) return RQ_OK;
     StreamCtx& c = it->second;
+    if (c.fused_pending) {
+        c.fused_pending = false;
+        HIPCHK(rq_tail_launch(c.fused_tail, c.fused_B, s));
+    }
     for (int p = 0; p < 2; ++p)
         if (c.tail_pending[p]) {
             HIPCHK(hipStreamWaitEvent(s, c.ev_tail[p], 0));
@@ -431,9 +447,19 @@ static int flush_tails(rq_index* idx, hipStream_t s) {
     return RQ_OK;
 }
 
+static int flush_all(rq_index* idx) {
+    if (idx->ctx.empty()) return RQ_OK;
+    if (int r = use_device(idx)) return r;
+    for (auto& kv : idx->ctx)
+        if (kv.second.fused_pending)
+            if (int r = flush_tails(idx, kv.first)) return r;
+    return RQ_OK;
+}
+
 // One pass of the pipeline for B queries.  nb < 0: exact scan (every bin re-scored, no corpus scan).
+// may_defer: the caller accepts results that are complete only after rq_search_flush_device ("pipeline" option).
 static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metric, int nb, float* d_scores, int64_t* d_rows,
-                        uint64_t* d_keys, int* d_status, hipStream_t s) {
+                        uint64_t* d_keys, int* d_status, hipStream_t s, bool may_defer = false) {
     if (idx->n == 0) return fill_empty(B, k, d_scores, d_rows, d_keys, d_status, s);
     const int R = idx->bin_tiles, per_quad = 16 / R, binrows = 4 * R;
     const int nquads = (int)((idx->n + 63) / 64);
@@ -449,9 +475,15 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     const bool fast = !exact && idx->fast_tail && m <= RQ_FAST_MAX_M && k <= RQ_FAST_MAX_K;
     const int64_t ncand = fast ? (int64_t)RQ_CAND_CAP : (int64_t)nb * binrows;
     StreamCtx& cx = idx->ctx[s];
-    const bool piped = fast && idx->pipeline != 0;
+    const bool piped = fast && may_defer && idx->pipeline == 1;
+    // fused mode: one scan launch per call (<= 64 queries), which carries the tail of the previous call
+    const bool fused = fast && may_defer && idx->pipeline == 2 && bpad == 64;
     int par = 0;
-    if (piped) {
+    if (fused) {
+        par = (int)(cx.calls++ & 1);
+        if (cx.fused_pending && cx.fused_tail.R != R) { if (int r = flush_tails(idx, s)) return r; }
+    } else if (piped) {
+        if (cx.fused_pending) { if (int r = flush_tails(idx, s)) return r; }
         if (!cx.tail) {
             // plain priority: a high-priority tail stream was measured to slow the scan it overlaps
             HIPCHK(hipStreamCreateWithFlags(&cx.tail, hipStreamNonBlocking));
@@ -499,7 +531,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             a.nq_valid = std::min(qb, B - blk * qb);
             a.wgmax = w.wgmax + (size_t)blk * qb * RQ_WGMAX_STRIDE;
             a.wgmax_stride = RQ_WGMAX_STRIDE;
-            const bool prof = idx->profile == 1 && idx->ev_used < 16384;
+            const bool prof = idx->profile == 1 && idx->ev_used < 16384 && (idx->scan_seq++ % (uint64_t)idx->profile_stride) == 0;
             if (prof) {
                 if (idx->ev_used == idx->events.size()) {
                     hipEvent_t e0, e1;
@@ -509,7 +541,11 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
                 }
                 HIPCHK(hipEventRecord(idx->events[idx->ev_used].first, s));
             }
-            if (qb == 128) HIPCHK(rq_scan_launch(a, 3, 4, 1, 8, R, nt, grid, s));
+            if (fused && cx.fused_pending) {
+                cx.fused_pending = false;
+                HIPCHK(rq_scan_tail_launch(a, cx.fused_tail, cx.fused_B, nt, grid, s));
+            } else if (fused) HIPCHK(rq_scan_launch(a, 2, 1, 1, 4, R, nt, grid, s));
+            else if (qb == 128) HIPCHK(rq_scan_launch(a, 3, 4, 1, 8, R, nt, grid, s));
             else HIPCHK(rq_scan_launch(a, idx->ring, idx->prefetch, idx->kstage, 4, R, nt, grid, s));
             if (prof) { HIPCHK(hipEventRecord(idx->events[idx->ev_used].second, s)); idx->ev_used++; }
         }
@@ -531,6 +567,13 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             ta.out_scores = d_scores; ta.out_rows = d_rows; ta.out_keys = d_keys; ta.out_status = d_status;
             ta.stop_after = idx->tail_stop;
             if (idx->tail_stop) w.counters_zero = false;   // a truncated tail does not reset its counters
+            if (fused) {
+                // the tail runs with the NEXT scan launch (or at the flush): it reads the workspace's own copy of the
+                // queries, so the caller's buffer is free as soon as this call's work has run
+                ta.q = w.q32; ta.dim = RQ_DPAD;
+                cx.fused_tail = ta; cx.fused_B = B; cx.fused_pending = true;
+                return RQ_OK;
+            }
             const bool tprof = idx->profile == 2 && idx->ev_used < 16384;   // profile = 2: time the tail instead of the scan
             if (tprof) {
                 if (idx->ev_used == idx->events.size()) {
@@ -577,7 +620,7 @@ extern "C" int rq_search_device(rq_index* idx, const float* d_queries, int B, in
     if (int r = use_device(idx)) return r;
     idx->t.searches++;
     idx->t.queries += B;
-    return run_pipeline(idx, d_queries, B, k, metric, nb_default(idx, k), d_scores, d_rows, d_keys, d_status, (hipStream_t)stream);
+    return run_pipeline(idx, d_queries, B, k, metric, nb_default(idx, k), d_scores, d_rows, d_keys, d_status, (hipStream_t)stream, true);
 }
 
 extern "C" int rq_search_flush_device(rq_index* idx, void* stream) {

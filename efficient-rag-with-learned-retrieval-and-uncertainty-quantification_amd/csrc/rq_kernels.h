@@ -92,6 +92,8 @@ struct RqTailArgs {
     float* out_scores; int64_t* out_rows; uint64_t* out_keys; int* out_status;
     int stop_after;                                // development: 0 = full kernel, 1..4 = return after phase A..D
 };
+// workgroups [0, scan_grid) run the scan `sa`, the rest the tail `ta` of an EARLIER batch (same bin_tiles R)
+hipError_t rq_scan_tail_launch(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, bool nt, int scan_grid, hipStream_t stream);
 hipError_t rq_tail_launch(const RqTailArgs& a, int B, hipStream_t stream);
 
 // Merge G sorted key lists per query (cross-shard): in [B][G*k] -> top-k scores/rows/keys.

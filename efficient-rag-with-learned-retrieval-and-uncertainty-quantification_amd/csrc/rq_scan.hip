@@ -23,6 +23,7 @@
 //     arg-max position) -- 2 * N/(4R)*64*4 B (2% of the corpus bytes at R=4) -- and wgmax[query][workgroup].
 #include "rq_device.h"
 #include "rq_kernels.h"
+#include "rq_tail_body.h"
 
 
 extern __shared__ __attribute__((aligned(16))) char rq_smem[];
@@ -39,8 +40,8 @@ __device__ __forceinline__ void rq_wait_vmcnt() {
 // their MFMAs (1, 4, 6 or 12); OCC: waves per SIMD the register allocation must allow; KS: stages per
 // tile (2: a stage is 16 half rows = 12 KiB; 1: a stage is 16 whole rows = 24 KiB contiguous in HBM);
 // QW: waves per workgroup = 16-query groups scored per corpus pass (4: 64 queries, 8: 128 queries).
-template <int S, int R, bool NT, int PF, int OCC, int KS, int QW>
-__global__ __launch_bounds__(64 * QW, OCC) void rq_scan_kernel(RqScanArgs a) {
+template <int S, int R, bool NT, int PF, int KS, int QW>
+__device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, const int G) {
     static_assert(S >= 2 && S <= 8, "ring depth");
     static_assert(PF == 1 || PF == 4 || PF == 6 || PF == 12, "fragment prefetch group");
     static_assert(R == 1 || R == 2 || R == 4, "tiles per bin");
@@ -76,7 +77,6 @@ __global__ __launch_bounds__(64 * QW, OCC) void rq_scan_kernel(RqScanArgs a) {
     for (int m = 0; m < 4; ++m)
         rbase[m] = (unsigned)(r16 * (CH * 16) + ((kg ^ (r16 & 3)) << 4) + ((m ^ (r16 >> 2)) << 6));
 
-    const int G = gridDim.x, b = blockIdx.x;
     const int nloc = (a.nquads > b) ? (a.nquads - b + G - 1) / G : 0;
     const int nst = nloc * NSTQ;
     const char* xb = (const char*)a.x;
@@ -190,6 +190,26 @@ __global__ __launch_bounds__(64 * QW, OCC) void rq_scan_kernel(RqScanArgs a) {
 }
 
 template <int S, int R, bool NT, int PF, int OCC, int KS, int QW>
+__global__ __launch_bounds__(64 * QW, OCC) void rq_scan_kernel(RqScanArgs a) {
+    rq_scan_body<S, R, NT, PF, KS, QW>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Fused launch: workgroups [0, scan_grid) scan the corpus for THIS batch, the others run the tail (threshold, fp64
+// re-score, final top-k) of the PREVIOUS batch of the same stream, whose scan finished with the previous launch.
+// One stream, no events: the tail's ~20 us hide under the scan, and the scan launches of consecutive batches never
+// overlap each other.  Scan variant: ring 2, whole-row stages, prefetch 1 (51 200 B of LDS, <= 168 VGPRs), so a CU
+// holds 2 scan workgroups + 1 tail workgroup (3 x 51 200 B <= 160 KB; the tail's 13.7 KB are carved from the ring).
+template <int R, bool NT, int NV4>
+__global__ __launch_bounds__(256, 3) void rq_scan_tail_kernel(RqScanArgs sa, RqTailArgs ta, int scan_grid, int tail_chunks) {
+    if ((int)blockIdx.x < scan_grid) {
+        rq_scan_body<2, R, NT, 1, 1, 4>(sa, (int)blockIdx.x, scan_grid);
+    } else {
+        const int t = (int)blockIdx.x - scan_grid;
+        rq_tail_body<R, NV4>(ta, t % tail_chunks, t / tail_chunks, tail_chunks, *reinterpret_cast<RqTailLds*>(rq_smem));
+    }
+}
+
+template <int S, int R, bool NT, int PF, int OCC, int KS, int QW>
 static hipError_t rq_scan_launch_t(const RqScanArgs& a, int grid, hipStream_t stream) {
     const size_t lds = (size_t)S * (24576 / KS) + 2 * QW * 256;   // ring + [2 parities][QW waves][64 row scales]
     static unsigned long long attr_done = 0;   // one bit per device
@@ -226,5 +246,41 @@ hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int ks, int qw, in
     RQ_CASE(2, 4, 2, 1, 4) RQ_CASE(3, 4, 2, 1, 4) RQ_CASE(3, 12, 2, 1, 4) RQ_CASE(2, 1, 3, 1, 4) RQ_CASE(4, 4, 2, 1, 4)
     RQ_CASE(3, 4, 2, 1, 8) RQ_CASE(4, 4, 2, 1, 8) RQ_CASE(2, 4, 2, 1, 8)
 #undef RQ_CASE
+    return hipErrorInvalidValue;
+}
+
+
+// ---- fused scan(batch i) + tail(batch i-1) -------------------------------------------------------------------
+template <int R, bool NT, int NV4>
+static hipError_t rq_scan_tail_launch_t(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, int scan_grid, hipStream_t stream) {
+    constexpr size_t lds = 2 * 24576 + 2 * 4 * 256;
+    static_assert(sizeof(RqTailLds) <= lds, "tail LDS must fit in the scan ring");
+    const int64_t chunks = (ta.nbins + 1024 * NV4 - 1) / (1024 * NV4);
+    if (chunks < 1 || chunks * tail_B > (1 << 24)) return hipErrorInvalidValue;
+    static unsigned long long attr_done = 0;   // one bit per device
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (!((attr_done >> (dev & 63)) & 1ull)) {
+        e = hipFuncSetAttribute((const void*)rq_scan_tail_kernel<R, NT, NV4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done |= 1ull << (dev & 63);
+    }
+    hipLaunchKernelGGL((rq_scan_tail_kernel<R, NT, NV4>), dim3((unsigned)(scan_grid + chunks * tail_B)), dim3(256), lds, stream, sa, ta,
+                       scan_grid, (int)chunks);
+    return hipGetLastError();
+}
+
+hipError_t rq_scan_tail_launch(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, bool nt, int scan_grid, hipStream_t stream) {
+    if (scan_grid <= 0 || tail_B < 1) return hipErrorInvalidValue;
+    if (ta.m < 1 || ta.m > RQ_FAST_MAX_M || ta.k < 1 || ta.k > RQ_FAST_MAX_K) return hipErrorInvalidValue;
+    const bool nv1 = ((ta.nbins + 1023) / 1024) * tail_B <= 1536;   // same rule as rq_tail_launch
+#define RQ_FCASE(RR) \
+    if (ta.R == RR) { \
+        if (nt) return nv1 ? rq_scan_tail_launch_t<RR, true, 1>(sa, ta, tail_B, scan_grid, stream) : rq_scan_tail_launch_t<RR, true, 4>(sa, ta, tail_B, scan_grid, stream); \
+        return nv1 ? rq_scan_tail_launch_t<RR, false, 1>(sa, ta, tail_B, scan_grid, stream) : rq_scan_tail_launch_t<RR, false, 4>(sa, ta, tail_B, scan_grid, stream); \
+    }
+    RQ_FCASE(4) RQ_FCASE(2) RQ_FCASE(1)
+#undef RQ_FCASE
     return hipErrorInvalidValue;
 }

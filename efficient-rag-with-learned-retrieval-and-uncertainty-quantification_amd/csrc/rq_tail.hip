@@ -18,210 +18,12 @@
 // Replaces reference rag_uq/streaming_index.py:355-368 (collection.query + `1 - distance`) after the scan.
 #include "rq_device.h"
 #include "rq_kernels.h"
-#include "rq_final_body.h"
+#include "rq_tail_body.h"
 
-#define RQ_TAIL_HITCAP 64      // candidate bins one workgroup can hold
-#define RQ_TAIL_JOBCAP 512     // row jobs one workgroup can hold
-
-// NV4: float4 loads of pooled values per thread (chunk = 1024 * NV4 bins per workgroup)
 template <int R, int NV4>
 __global__ __launch_bounds__(256) void rq_tail_kernel(RqTailArgs a) {
-    __shared__ __attribute__((aligned(16))) float qs[RQ_DPAD];   // the raw query, shared by the four waves
-    __shared__ double qpart[4];
-    __shared__ float thr_s;
-    __shared__ int nhit_s, njob_s, base_s, last_s, total_s, ovf_s;
-    __shared__ int hits[RQ_TAIL_HITCAP];
-    __shared__ int jobs[RQ_TAIL_JOBCAP];      // (hit << 4) | position of the row inside its bin
-    __shared__ RqFinalLds flds;
-    const int q = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float NEG_INF = -__builtin_huge_valf();
-    constexpr int binrows = 4 * R;
-    constexpr int CHUNK = 1024 * NV4;
-
-    // ---- independent loads first: this chunk of pooled values, the query (-> LDS), (wave 0) the partition maxima
-    const float* p = a.pooled + (int64_t)q * a.pooled_stride;
-    const int64_t cbase = (int64_t)blockIdx.x * CHUNK + tid * 4;
-    float4 v4[NV4];
-#pragma unroll
-    for (int u = 0; u < NV4; ++u) {
-        const int64_t i = cbase + (int64_t)u * 1024;
-        v4[u] = (i < a.pooled_stride) ? *(const float4*)(p + i) : make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
-    }
-    float qmine[3];
-    {
-        const float* qp = a.q + (size_t)q * a.dim;
-#pragma unroll
-        for (int pp = 0; pp < 3; ++pp) { const int i = pp * 256 + tid; qmine[pp] = i < a.dim ? qp[i] : 0.f; qs[i] = qmine[pp]; }
-    }
-    if (tid == 0) { thr_s = NEG_INF; nhit_s = 0; njob_s = 0; last_s = 0; }
-
-    // ---- A. threshold: ballot radix select (wave 0) of the m-th largest partition maximum, truncated to the
-    //      top 20 key bits (a slightly lower, still valid threshold).  m <= 24: 64 partitions (one per lane),
-    //      else 256 (four per lane): more partitions = tighter threshold when m is large.
-    if (wave == 0) {
-        const float* w = a.wgmax + (int64_t)q * a.wgmax_stride;
-        uint32_t prefix = 0;
-        if (a.m <= 24) {
-            float v = NEG_INF;
-            for (int j = lane; j < a.nwg; j += 64) v = fmaxf(v, w[j]);
-            const uint32_t key = rq_mono32(v);
-            for (int bit = 31; bit >= 12; --bit) {
-                const uint32_t t = prefix | (1u << bit);
-                if (__popcll(__ballot(key >= t)) >= a.m) prefix = t;   // uniform
-            }
-        } else if (a.m <= 256) {
-            uint32_t key[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float v = NEG_INF;
-                for (int j = i * 64 + lane; j < a.nwg; j += 256) v = fmaxf(v, w[j]);
-                key[i] = rq_mono32(v);
-            }
-            for (int bit = 31; bit >= 12; --bit) {
-                const uint32_t t = prefix | (1u << bit);
-                int c = 0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) c += __popcll(__ballot(key[i] >= t));
-                if (c >= a.m) prefix = t;
-            }
-        }
-        // prefix == 0 (fewer than m partitions hold anything): unmono gives NaN -> use -inf = "every bin"
-        if (lane == 0) thr_s = prefix > rq_mono32(NEG_INF) ? rq_unmono32(prefix) : NEG_INF;
-    }
-    __syncthreads();
-    const float T = thr_s;
-    if (a.stop_after == 1) { if (tid == 0 && blockIdx.x == 0) a.out_status[q] = (int)T; return; }
-
-    // ---- B. bins of this chunk that reach the threshold -> row jobs
-    {
-        const uint32_t* ax = a.aux + (int64_t)q * a.pooled_stride;
-#pragma unroll
-        for (int u = 0; u < NV4; ++u) {
-            const float xs[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int64_t i = cbase + (int64_t)u * 1024 + e;
-                if (i < a.nbins && xs[e] >= T) {
-                    const int h = atomicAdd(&nhit_s, 1);
-                    if (h < RQ_TAIL_HITCAP) {
-                        hits[h] = (int)i;
-                        const uint32_t w = ax[i];
-                        const bool whole = rq_aux_second(w) >= T;          // a second row of the bin may reach T too
-                        const int nj = whole ? binrows : 1;
-                        const int j0 = atomicAdd(&njob_s, nj);
-                        for (int j = 0; j < nj; ++j)
-                            if (j0 + j < RQ_TAIL_JOBCAP) jobs[j0 + j] = (h << 4) | (whole ? j : (int)(w & 15u));
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    const int nh = nhit_s;
-    const int njob_all = njob_s;
-    const int njob = njob_all < RQ_TAIL_JOBCAP ? njob_all : RQ_TAIL_JOBCAP;
-    if (tid == 0) {
-        base_s = njob_all ? atomicAdd(&a.rowcount[q], njob_all) : 0;
-        if (nh > RQ_TAIL_HITCAP || njob_all > RQ_TAIL_JOBCAP) atomicOr(&a.ovf[q], 1);
-    }
-    // fp64 norm of the query (only workgroups with jobs, and later the last one, need it)
-    auto query_norm = [&]() -> double {
-        double ssq = 0.0;
-#pragma unroll
-        for (int pp = 0; pp < 3; ++pp) ssq += (double)qmine[pp] * (double)qmine[pp];
-        ssq = rq_wave_sum(ssq);
-        if (lane == 0) qpart[wave] = ssq;
-        __syncthreads();
-        const double r = sqrt((qpart[0] + qpart[1]) + (qpart[2] + qpart[3]));
-        __syncthreads();
-        return r;
-    };
-    double qn = -1.0;
-    if (nh > 0) qn = query_norm();   // uniform branch (nh comes from LDS after a barrier); contains barriers, which
-                                     // also make base_s (thread 0's returned atomic) visible to every wave
-    else __syncthreads();
-    if (a.stop_after == 2) return;
-
-    // ---- C. exact re-score of the job rows: 16 lanes per row (sub = lane & 15 owns elements pp*128 + 8*sub + e),
-    //      a wave takes 8 jobs per round (two groups of 4 rows, all 12 loads per lane in flight before the math)
-    if (nh > 0 && qn != 0.0) {
-        const int base = base_s;
-        const int sub = lane & 15, rloc = lane >> 4;
-        const char* xb = (const char*)a.x;
-        uint64_t* out = a.cand + (int64_t)q * RQ_CAND_CAP;
-        for (int j0 = wave * 8; j0 < njob; j0 += 32) {
-            rq_half8 xv[2][6];
-            int64_t rows[2];
-            double rn[2];
-            int pos[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int jb = j0 + u * 4 + rloc;
-                const bool live = jb < njob;
-                const int job = jobs[live ? jb : 0];
-                pos[u] = (live && base + jb < RQ_CAND_CAP) ? base + jb : -1;   // -1: nothing stored (padding or list full)
-                rows[u] = rq_bin_row((int64_t)hits[job >> 4], R, job & 15);
-                const int64_t rr = rows[u] < a.n_rows ? rows[u] : 0;
-                rn[u] = a.rownorm64[rr];
-                const char* r = xb + rr * (RQ_DPAD * 2) + sub * 16;
-#pragma unroll
-                for (int pp = 0; pp < 6; ++pp) xv[u][pp] = *(const rq_half8*)(r + pp * 256);
-            }
-            double dot[2] = {0.0, 0.0};
-#pragma unroll
-            for (int pp = 0; pp < 6; ++pp) {
-                const float4 qlo = *(const float4*)&qs[pp * 128 + 8 * sub], qhi = *(const float4*)&qs[pp * 128 + 8 * sub + 4];
-                const float qq[8] = {qlo.x, qlo.y, qlo.z, qlo.w, qhi.x, qhi.y, qhi.z, qhi.w};
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) dot[u] += (double)qq[e] * (double)(float)xv[u][pp][e];
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                double d = dot[u];
-#pragma unroll
-                for (int off = 8; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
-                if (sub == 0 && pos[u] >= 0) {
-                    uint64_t key = 0;                                       // stays 0 for a row beyond the shard's end
-                    if (rows[u] < a.n_rows) {
-                        double sc = d;
-                        if (a.metric == 0) sc = d / (qn * rn[u] + 1e-30);
-                        key = rq_make_key(rq_sanitize((float)sc), (uint32_t)rows[u]);
-                    }
-                    // write-through (sc1) store: visible to the last workgroup without a release fence
-                    __hip_atomic_store(&out[pos[u]], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
-    }
-    if (a.stop_after == 3) return;
-
-    // ---- D. publish (MI355X_MICROARCH.md "Valid forms", first table row)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        const int ticket = __hip_atomic_fetch_add(&a.done[q], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ticket == (int)gridDim.x - 1) {
-            total_s = __hip_atomic_load(&a.rowcount[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ovf_s = __hip_atomic_load(&a.ovf[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // counters back to zero for the next launch on this workspace
-            __hip_atomic_store(&a.rowcount[q], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&a.ovf[q], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&a.done[q], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last_s = 1;
-        }
-    }
-    __syncthreads();
-    if (!last_s || a.stop_after == 4) return;
-    if (qn < 0.0) qn = query_norm();   // uniform: this workgroup had no hits of its own
-
-    RqFinalCore c;
-    c.cand = a.cand + (int64_t)q * RQ_CAND_CAP; c.metric = a.metric; c.eps = a.eps;
-    c.max_row_norm = a.max_row_norm; c.k = a.k; c.row_offset = a.row_offset; c.n_rows = a.n_rows;
-    c.out_scores = a.out_scores + (int64_t)q * a.k; c.out_rows = a.out_rows + (int64_t)q * a.k;
-    c.out_keys = a.out_keys ? a.out_keys + (int64_t)q * a.k : nullptr; c.out_status = a.out_status + q;
-    rq_final_body(c, total_s, ovf_s, T, qn, flds);
+    __shared__ RqTailLds lds;
+    rq_tail_body<R, NV4>(a, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, lds);
 }
 
 template <int NV4>

@@ -82,10 +82,14 @@ int rq_search(rq_index* idx, const float* queries, int B, int k, int metric, flo
  * Calls on different streams may overlap; each stream has its own workspace. */
 int rq_search_device(rq_index* idx, const float* d_queries, int B, int k, int metric, float* d_scores, int64_t* d_rows,
                      uint64_t* d_keys, int* d_status, void* stream);
-/* With option "pipeline" = 1 the tail of a search (bin collection, fp64 re-score, final top-k) runs on an
- * internal stream so that the next corpus scan on `stream` starts at once; results of earlier
- * rq_search_device calls are then ordered on `stream` only after this call (rq_search_fixup_device
- * implies it). */
+/* Deferred tails (option "pipeline"): the tail of a search (threshold, fp64 re-score, final top-k) is taken off
+ * the critical path of `stream` so that the next corpus scan starts at once.
+ *   1: the tail runs on an internal stream (two cross-stream events per call);
+ *   2: the tail of call i is executed by extra workgroups of the scan launch of call i+1 on the same stream (no
+ *      events, scans never overlap each other; calls of <= 64 queries, k <= 128).
+ * In both modes the outputs of rq_search_device calls are complete on `stream` only after this call
+ * (rq_search_fixup_device implies it); output buffers must stay valid until then.  Mode 1 also reads d_queries
+ * until then, mode 2 keeps its own copy. */
 int rq_search_flush_device(rq_index* idx, void* stream);
 /* Synchronises `stream`, re-runs the queries whose d_status is non-zero with wider candidate sets /
  * the exact scan, patches d_scores/d_rows/d_keys/d_status in place.  Returns the number repaired. */
@@ -101,7 +105,7 @@ int rq_merge_keys_device(const uint64_t* d_keys_in, int n_per_query, int B, int 
  * (kstage, ring, prefetch) triples built are listed in csrc/rq_scan.hip, others fail with RQ_EHIP at search time),
  * "bin_tiles" (1,2,4: bin = 4*bin_tiles rows),
  * "wg_per_cu", "nt" (non-temporal corpus loads: 0, 1, -1 = auto), "slack_bins" (extra bins beyond k, -1 = auto),
- * "eps" (certificate bound, <0 = derived default), "profile" (record HIP events around every scan launch),
+ * "eps" (certificate bound, <0 = derived default), "profile" (record HIP events around every scan launch; "profile_stride" n: around every n-th),
  * "prefetch" (LDS fragments read ahead of their MFMAs: 1, 4, 6, 12), "fast_tail" (0 = generic sorted tail),
  * "pipeline" (see rq_search_flush_device). */
 int rq_set_option(rq_index* idx, const char* name, double value);

@@ -136,7 +136,7 @@ def test_clustered_near_ties():
     idx.close()
 
 
-@pytest.mark.parametrize("opts", [dict(fast_tail=0), dict(fast_tail=0, bin_tiles=1), dict(pipeline=1), dict(bin_tiles=2), dict(wide_batch=0),
+@pytest.mark.parametrize("opts", [dict(fast_tail=0), dict(fast_tail=0, bin_tiles=1), dict(pipeline=1), dict(pipeline=2), dict(bin_tiles=2), dict(wide_batch=0),
                                   dict(bin_tiles=1), dict(wg_per_cu=1), dict(slack_bins=0),
                                   # every scan instantiation built in csrc/rq_scan.hip: (kstage, ring, prefetch)
                                   dict(kstage=1, ring=2, prefetch=1), dict(kstage=1, ring=2, prefetch=4), dict(kstage=1, ring=3, prefetch=4),
@@ -151,6 +151,57 @@ def test_every_kernel_variant_is_exact(corpus100k, opts):
         idx.set_option(name, v)
     _check(idx, x16[:30_011], orc.synthetic_queries(64, 768, seed=1), 10)
     _check(idx, x16[:30_011], orc.synthetic_queries(3, 768, seed=2), 100)
+    idx.close()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_deferred_tails_over_many_batches(mode):
+    """pipeline = 1 (internal tail stream) and 2 (the tail of batch i rides in the scan launch of batch i+1):
+    a train of calls on one stream, batch sizes / k / bin_tiles changing on the way, rows appended in the middle,
+    the query buffer overwritten right after every call -- every batch must come out exact after the flush."""
+    import torch
+    x16 = orc.synthetic_corpus(70_000, 768, seed=77)
+    x16[500:520] = x16[3]
+    idx = nat.NativeIndex(768, 0)
+    idx.add_f16(x16[:60_000])
+    idx.set_option("pipeline", mode)
+    dev = torch.device("cuda:0")
+    st = torch.cuda.Stream(device=dev)
+    plan = [(64, 10, 4), (64, 10, 4), (17, 10, 4), (64, 100, 4), (64, 10, 2), (64, 10, 2), (100, 10, 4), (64, 5, 4), (1, 1, 1), (64, 10, 4)]
+    outs, n_rows = [], 60_000
+    scratch = torch.zeros((128, 768), device=dev)
+    with torch.cuda.stream(st):
+        for step, (B, k, R) in enumerate(plan):
+            if step == 5:
+                idx.add_f16(x16[60_000:])            # drains + appends; a deferred tail must have been launched first
+                n_rows = 70_000
+            idx.set_option("bin_tiles", R)
+            q = orc.synthetic_queries(B, 768, seed=900 + step)
+            if step == 7:
+                q[0] = x16[3].astype(np.float32)     # 21 exact duplicates: ties by row id
+            dq = torch.from_numpy(q).to(dev)
+            src = dq
+            if mode == 2:                            # mode 2 keeps its own copy: the caller's buffer may be reused at once
+                scratch[:B].copy_(dq); src = scratch
+            sc = torch.empty((B, k), device=dev); rw = torch.empty((B, k), device=dev, dtype=torch.int64)
+            ky = torch.empty((B, k), device=dev, dtype=torch.int64); stt = torch.empty((B,), device=dev, dtype=torch.int32)
+            idx.search_device(src, B, k, 0, sc, rw, ky, stt, st.cuda_stream)
+            if mode == 2:
+                scratch[:B].add_(1.0)
+            outs.append((q, dq, n_rows, B, k, sc, rw, ky, stt))
+        idx.search_flush_device(st.cuda_stream)
+        st.synchronize()
+        uncertified = sum(int(o[-1].sum()) for o in outs)
+        assert uncertified <= 2                      # at most the duplicate query may need the wider pass
+        for q, dq, n, B, k, sc, rw, ky, stt in outs:
+            if n == 70_000:                          # (batches searched before the append cannot be repaired against the grown shard)
+                idx.search_fixup_device(dq, B, k, 0, sc, rw, ky, stt, st.cuda_stream)
+    st.synchronize()
+    for q, dq, n, B, k, sc, rw, ky, stt in outs:
+        es, er = orc.dense_topk(q, x16[:n], k)
+        assert int(stt.sum()) == 0
+        assert np.array_equal(rw.cpu().numpy(), er)
+        assert float(np.abs(sc.cpu().numpy() - es).max()) <= SCORE_TOL
     idx.close()
 
 

@@ -3,7 +3,7 @@
     python tools/make_profiles.py r01
 
 expects  gpurun_out/prof_bench/*/*kernel_stats.csv      rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline
-         gpurun_out/pmc_fetch/*/*counter_collection.csv  rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --streams 1
+         gpurun_out/pmc_fetch/*/*counter_collection.csv  rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline
          gpurun_out/pmc_write/*/*counter_collection.csv  rocprofv3 --pmc WRITE_SIZE -- (same)
 """
 import csv, glob, json, os, sys
@@ -49,13 +49,16 @@ for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     f = first(f"{name}/*/*counter_collection.csv")
     if not f:
         continue
-    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "rq_scan" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+    recs = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+    fused = [r for r in recs if "rq_scan_tail" in r["Kernel_Name"]]     # the bench default: scan + previous batch's tail
+    vals = [float(r["Counter_Value"]) for r in (fused or [r for r in recs if "rq_scan" in r["Kernel_Name"]])]
+    pmc_kernel = "rq_scan_tail_kernel" if fused else "rq_scan_kernel"
     pmc[counter] = {"launches": len(vals), "mean": sum(vals) / len(vals), "min": min(vals), "max": max(vals), "unit": "KiB (rocprofv3 derived counter)"}
 if "FETCH_SIZE" in pmc:
     fetch = pmc["FETCH_SIZE"]["mean"] * 1024
     write = pmc.get("WRITE_SIZE", {"mean": 0.0})["mean"] * 1024
     summary = {
-        "kernel": "rq_scan_kernel", "workload": "1000000x768 fp16 corpus, 64 queries per launch",
+        "kernel": pmc_kernel, "workload": "1000000x768 fp16 corpus, 64 queries per launch",
         "counters": pmc,
         "correction": "MI355X_MICROARCH.md 'HBM': on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced "
                       "streaming read (16 B/lane, global_load and LDS-DMA alike) -> read bytes = 2 * FETCH_SIZE * 1024; "
