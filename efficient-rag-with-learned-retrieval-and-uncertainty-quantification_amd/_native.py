@@ -62,6 +62,7 @@ _SIGNATURES = {
     "rq_merge_keys_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
     "rq_debug_pooled": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
+    "rq_debug_read_bandwidth": (C.c_double, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "rq_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
     "rq_get_option": (C.c_double, [C.c_void_p, C.c_char_p]),
     "rq_get_timing": (C.c_int, [C.c_void_p, C.POINTER(rq_timing)]),
@@ -218,6 +219,13 @@ class NativeIndex:
         out = np.empty((int(max_bins),), dtype=np.float32)
         n = _check(self._lib.rq_debug_pooled(self._h, C.c_void_p(stream), int(query), _ptr(out), int(max_bins)), "rq_debug_pooled")
         return out[:n]
+
+    def read_bandwidth(self, iters: int = 20, nt: int = -1, wg_per_cu: int = 8) -> float:
+        """GB/s of a plain streaming read of the stored shard (measurement yardstick, see include/rq.h)."""
+        v = float(self._lib.rq_debug_read_bandwidth(self._h, int(iters), int(nt), int(wg_per_cu)))
+        if v < 0:
+            raise RqError(f"rq_debug_read_bandwidth: {last_error()}")
+        return v
 
     # -- knobs / timing -----------------------------------------------------------------------
     def set_option(self, name: str, value: float) -> None:

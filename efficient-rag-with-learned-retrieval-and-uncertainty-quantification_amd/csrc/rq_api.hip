@@ -100,7 +100,7 @@ struct rq_index {
     double max_row_norm = 0.0;
     uint64_t scan_seq = 0;         // scan launches seen while profile = 1 (every profile_stride-th one is timed)
     // options
-    int ring = 2, prefetch = 1, kstage = 1, wide_batch = 1, bin_tiles = 4, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, profile_stride = 1, fast_tail = 1, pipeline = 0, tail_stop = 0;
+    int ring = 2, prefetch = 1, kstage = 1, wide_batch = 1, bin_tiles = 4, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, profile_stride = 1, scan_nostore = 0, fast_tail = 1, pipeline = 0, tail_stop = 0;
     double eps = -1.0;
     std::map<hipStream_t, StreamCtx> ctx;
     hipStream_t own_stream = nullptr;
@@ -338,6 +338,7 @@ extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     else if (s == "slack_bins") idx->slack_bins = (int)v;
     else if (s == "eps") idx->eps = v;
     else if (s == "profile") idx->profile = (int)v;
+    else if (s == "scan_nostore") idx->scan_nostore = (int)v;   // timing experiments only: the scan writes nothing (results invalid)
     else if (s == "profile_stride") { if (v < 1) return set_err(RQ_EINVAL, "profile_stride must be >= 1"); idx->profile_stride = (int)v; }
     else if (s == "fast_tail") idx->fast_tail = (int)v;
     else if (s == "pipeline") { if (v != 0 && v != 1 && v != 2) return set_err(RQ_EINVAL, "pipeline must be 0, 1 or 2"); if (int r = flush_all(idx)) return r; idx->pipeline = (int)v; }
@@ -528,7 +529,8 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             a.pooled_stride = w.pooled_stride;
             a.n_rows = idx->n;
             a.nquads = nquads;
-            a.nq_valid = std::min(qb, B - blk * qb);
+            a.nq_valid = idx->scan_nostore == 1 ? 0 : std::min(qb, B - blk * qb);
+            a.dev_layout = idx->scan_nostore;
             a.wgmax = w.wgmax + (size_t)blk * qb * RQ_WGMAX_STRIDE;
             a.wgmax_stride = RQ_WGMAX_STRIDE;
             const bool prof = idx->profile == 1 && idx->ev_used < 16384 && (idx->scan_seq++ % (uint64_t)idx->profile_stride) == 0;
@@ -725,6 +727,38 @@ extern "C" int rq_merge_keys_device(const uint64_t* d_keys_in, int n_per_query, 
     if (!d_keys_in || !d_scores || !d_rows || B < 1 || k < 1 || k > RQ_MAX_K || n_per_query < 0) return set_err(RQ_EINVAL, "bad merge arguments");
     HIPCHK(rq_merge_keys_launch(d_keys_in, n_per_query, B, k, d_scores, d_rows, d_keys_out, (hipStream_t)stream));
     return RQ_OK;
+}
+
+// ---- measurement hook: plain streaming read of the shard (see rq_read_probe_kernel) ------------------------
+extern "C" double rq_debug_read_bandwidth(rq_index* idx, int iters, int nt, int wg_per_cu) {
+    if (!idx || iters < 1 || iters > 1000 || wg_per_cu < 1 || wg_per_cu > 32) { set_err(RQ_EINVAL, "bad arguments"); return -1.0; }
+    if (use_device(idx)) return -1.0;
+    if (idx->n == 0) { set_err(RQ_EINVAL, "empty index"); return -1.0; }
+    if (flush_all(idx)) return -1.0;
+    const int64_t bytes = idx->n * (int64_t)(RQ_DPAD * 2);
+    const bool use_nt = nt < 0 ? bytes > ((int64_t)208 << 20) : nt != 0;
+    uint32_t* sink = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    double gbs = -1.0;
+    hipStream_t s = idx->own_stream;
+    do {
+        if (hipMalloc((void**)&sink, 64) != hipSuccess) break;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) break;
+        const int grid = idx->cu_count * wg_per_cu;
+        if (rq_read_probe_launch(idx->x, bytes, use_nt, grid, sink, s) != hipSuccess) break;   // warm-up
+        if (hipEventRecord(e0, s) != hipSuccess) break;
+        bool ok = true;
+        for (int i = 0; i < iters && ok; ++i) ok = rq_read_probe_launch(idx->x, bytes, use_nt, grid, sink, s) == hipSuccess;
+        if (!ok || hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) break;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0.f) break;
+        gbs = (double)bytes * iters / (ms * 1e-3) / 1e9;
+    } while (0);
+    if (gbs < 0) set_err(RQ_EHIP, "read probe failed: %s", hipGetErrorString(hipGetLastError()));
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (sink) (void)hipFree(sink);
+    return gbs;
 }
 
 // ---- test hook: the scan's per-bin maxima of the last search on `stream` ---------------------------------

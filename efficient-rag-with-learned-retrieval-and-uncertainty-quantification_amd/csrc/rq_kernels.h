@@ -15,6 +15,7 @@ struct RqScanArgs {
     int nq_valid;             // queries of this block that are real (<= QB)
     float* wgmax;             // [QB][wgmax_stride] best pooled value per (query, scan workgroup)
     int wgmax_stride;         // >= grid
+    int dev_layout;           // timing experiments only (0 = normal): 2 = each wave writes its bins of a quad as one 256 B run
 };
 #define RQ_WGMAX_STRIDE 1024   // scan grids never exceed this many workgroups
 
@@ -99,3 +100,4 @@ hipError_t rq_tail_launch(const RqTailArgs& a, int B, hipStream_t stream);
 // Merge G sorted key lists per query (cross-shard): in [B][G*k] -> top-k scores/rows/keys.
 hipError_t rq_merge_keys_launch(const uint64_t* keys, int n_per_query, int B, int k, float* out_scores, int64_t* out_rows,
                                 uint64_t* out_keys, hipStream_t stream);
+hipError_t rq_read_probe_launch(const void* x, int64_t bytes, bool nt, int grid, uint32_t* sink, hipStream_t stream);

@@ -164,7 +164,8 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
 #pragma unroll
         for (int u = 0; u < 4 / R; ++u) wmax = fmaxf(wmax, binmax[u]);
         if (16 * wave + r16 < a.nq_valid) {
-            const int64_t off = (int64_t)(16 * wave + r16) * a.pooled_stride + quad * (16 / R) + kg * (4 / R);
+            int64_t off = (int64_t)(16 * wave + r16) * a.pooled_stride + quad * (16 / R) + kg * (4 / R);
+            if (a.dev_layout == 2) off = quad * (64 * 16 / R) + (16 * wave + r16) * (16 / R) + kg * (4 / R);
             float* dst = a.pooled + off;
             // aux word per bin: [31:16] second-largest score rounded UP to 16 bits (an upper bound), [3:0] arg-max position
             uint32_t ax[4 / R];

@@ -131,6 +131,11 @@ rq_index* rq_load(const char* path, int n_devices, const int* device_ids);
  * (bin b of 4*bin_tiles rows, see csrc/rq_device.h rq_bin_row) to the host.  Returns the number of bins copied. */
 int64_t rq_debug_pooled(rq_index* idx, void* stream, int query, float* out, int64_t max_bins);
 
+/* Measurement hook: GB/s of a plain streaming read (16-byte loads, nothing else) of the stored shard, averaged over
+ * `iters` back-to-back passes -- what THIS GPU delivers right now, the yardstick for the scan kernel's rate.
+ * nt: non-temporal loads 0 / 1 / -1 = the scan's own rule.  Negative on error. */
+double rq_debug_read_bandwidth(rq_index* idx, int iters, int nt, int wg_per_cu);
+
 const char* rq_last_error(void);
 const char* rq_version(void);
 
