@@ -45,17 +45,16 @@ static int set_err(int code, const char* fmt, ...) {
 // ---------------------------------------------------------------------------------------------
 struct Workspace {
     int bcap = 0;                 // query slots (multiple of 64)
-    int64_t pooled_stride = 0;    // floats per query
+    int64_t bins_stride = 0;      // bin records per query
     int64_t binkeys_cap = 0;      // entries per query
     size_t cand_elems = 0;        // candidate keys allocated in total (queries of a call x keys per query)
     _Float16* qh = nullptr;
     float* q32 = nullptr;
     double* qn = nullptr;
-    float* pooled = nullptr;
+    uint2* bins = nullptr;        // [bcap][bins_stride] scan output: one record per (query, quad), see rq_device.h
     uint64_t* binkeys = nullptr;
     uint64_t* cand = nullptr;
     float* wgmax = nullptr;       // [bcap][RQ_WGMAX_STRIDE]
-    uint32_t* aux = nullptr;      // [bcap][pooled_stride] second-largest score (16-bit upper bound) | arg-max position per bin
     int* rowcount = nullptr;      // [bcap] fast tail: candidate rows appended so far
     float* thr = nullptr;         // [bcap]
     int* done = nullptr;          // [bcap] fast tail: workgroups of the query that have finished
@@ -100,7 +99,7 @@ struct rq_index {
     double max_row_norm = 0.0;
     uint64_t scan_seq = 0;         // scan launches seen while profile = 1 (every profile_stride-th one is timed)
     // options
-    int ring = 2, prefetch = 1, kstage = 1, wide_batch = 1, bin_tiles = 4, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, profile_stride = 1, scan_nostore = 0, fast_tail = 1, pipeline = 0, tail_stop = 0;
+    int ring = 2, prefetch = 1, kstage = 1, wide_batch = 1, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, profile_stride = 1, scan_nostore = 0, fast_tail = 1, pipeline = 0, tail_stop = 0;
     double eps = -1.0;
     std::map<hipStream_t, StreamCtx> ctx;
     hipStream_t own_stream = nullptr;
@@ -120,11 +119,8 @@ struct rq_index {
 static const float RQ_EPS_DEFAULT = 7.0e-4f;
 
 static int nb_default(const rq_index* idx, int k) {
-    const int per_quad = 16 / idx->bin_tiles;
-    int slack = idx->slack_bins >= 0 ? idx->slack_bins : std::max(8, k / 8);
-    int nb = k + slack;
-    nb = (nb + per_quad - 1) / per_quad * per_quad;
-    return nb;
+    const int slack = idx->slack_bins >= 0 ? idx->slack_bins : std::max(8, k / 8);
+    return k + slack;
 }
 static const int RQ_NB_MAX = 3071;   // select kernel: m = nb + 1 <= RQ_SEL_L - RQ_SEL_THREADS
 
@@ -209,7 +205,7 @@ extern "C" rq_index* rq_index_create(int dim, int n_devices, const int* device_i
 }
 
 static void free_ws(Workspace& w) {
-    void* p[] = {w.qh, w.q32, w.qn, w.pooled, w.binkeys, w.cand, w.wgmax, w.aux, w.rowcount, w.thr, w.done, w.ovf, w.fix_q, w.fix_scores, w.fix_rows, w.fix_keys, w.fix_status};
+    void* p[] = {w.qh, w.q32, w.qn, w.bins, w.binkeys, w.cand, w.wgmax, w.rowcount, w.thr, w.done, w.ovf, w.fix_q, w.fix_scores, w.fix_rows, w.fix_keys, w.fix_status};
     for (void* q : p) if (q) (void)hipFree(q);
     w = Workspace();
 }
@@ -332,13 +328,12 @@ extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     else if (s == "wide_batch") idx->wide_batch = (int)v;
     else if (s == "kstage") { if (v != 1 && v != 2) return set_err(RQ_EINVAL, "kstage must be 1 or 2"); idx->kstage = (int)v; }
     else if (s == "prefetch") { if (v != 1 && v != 4 && v != 6 && v != 12) return set_err(RQ_EINVAL, "prefetch must be 1, 4, 6 or 12"); idx->prefetch = (int)v; }
-    else if (s == "bin_tiles") { if (v != 1 && v != 2 && v != 4) return set_err(RQ_EINVAL, "bin_tiles must be 1, 2 or 4"); idx->bin_tiles = (int)v; }
     else if (s == "wg_per_cu") { if (v < 1 || v > 8) return set_err(RQ_EINVAL, "wg_per_cu must be 1..8"); idx->wg_per_cu = (int)v; }
     else if (s == "nt") idx->nt = (int)v;
     else if (s == "slack_bins") idx->slack_bins = (int)v;
     else if (s == "eps") idx->eps = v;
     else if (s == "profile") idx->profile = (int)v;
-    else if (s == "scan_nostore") idx->scan_nostore = (int)v;   // timing experiments only: the scan writes nothing (results invalid)
+    else if (s == "scan_nostore") idx->scan_nostore = (int)v;   // timing experiments only: 1 = the scan writes nothing (results invalid), 2 = plain instead of non-temporal record stores
     else if (s == "profile_stride") { if (v < 1) return set_err(RQ_EINVAL, "profile_stride must be >= 1"); idx->profile_stride = (int)v; }
     else if (s == "fast_tail") idx->fast_tail = (int)v;
     else if (s == "pipeline") { if (v != 0 && v != 1 && v != 2) return set_err(RQ_EINVAL, "pipeline must be 0, 1 or 2"); if (int r = flush_all(idx)) return r; idx->pipeline = (int)v; }
@@ -353,7 +348,6 @@ extern "C" double rq_get_option(const rq_index* idx, const char* name) {
     if (s == "prefetch") return idx->prefetch;
     if (s == "kstage") return idx->kstage;
     if (s == "wide_batch") return idx->wide_batch;
-    if (s == "bin_tiles") return idx->bin_tiles;
     if (s == "wg_per_cu") return idx->wg_per_cu;
     if (s == "nt") return idx->nt;
     if (s == "slack_bins") return idx->slack_bins;
@@ -393,11 +387,10 @@ static int ensure_ws(Workspace& w, int bpad, int64_t stride, int64_t m, size_t c
         if (int r = ensure(w.ovf, (size_t)bcap)) return r;
         w.counters_zero = false;
     }
-    if (regrow_b || stride > w.pooled_stride) {
-        const int64_t st = std::max(stride, w.pooled_stride);
-        if (int r = ensure(w.pooled, (size_t)bcap * st)) return r;
-        if (int r = ensure(w.aux, (size_t)bcap * st)) return r;
-        w.pooled_stride = st;
+    if (regrow_b || stride > w.bins_stride) {
+        const int64_t st = std::max(stride, w.bins_stride);
+        if (int r = ensure(w.bins, (size_t)bcap * st)) return r;
+        w.bins_stride = st;
     }
     if (regrow_b || m > w.binkeys_cap) {
         const int64_t mm = std::max(m, w.binkeys_cap);
@@ -462,9 +455,9 @@ static int flush_all(rq_index* idx) {
 static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metric, int nb, float* d_scores, int64_t* d_rows,
                         uint64_t* d_keys, int* d_status, hipStream_t s, bool may_defer = false) {
     if (idx->n == 0) return fill_empty(B, k, d_scores, d_rows, d_keys, d_status, s);
-    const int R = idx->bin_tiles, per_quad = 16 / R, binrows = 4 * R;
+    const int binrows = RQ_BIN_ROWS;
     const int nquads = (int)((idx->n + 63) / 64);
-    const int64_t nbins = (int64_t)nquads * per_quad;
+    const int64_t nbins = nquads;   // bin = quad
     const bool exact = nb < 0 || nb >= nbins;
     if (exact) nb = (int)std::min<int64_t>(nbins, INT32_MAX / 64);
     if (!exact && nb > RQ_NB_MAX) return set_err(RQ_EINVAL, "nb %d too large", nb);
@@ -482,7 +475,6 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     int par = 0;
     if (fused) {
         par = (int)(cx.calls++ & 1);
-        if (cx.fused_pending && cx.fused_tail.R != R) { if (int r = flush_tails(idx, s)) return r; }
     } else if (piped) {
         if (cx.fused_pending) { if (int r = flush_tails(idx, s)) return r; }
         if (!cx.tail) {
@@ -524,13 +516,12 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             a.x = idx->x;
             a.row_scale = scale;
             a.qh = w.qh + (size_t)blk * qb * RQ_DPAD;
-            a.pooled = w.pooled + (size_t)blk * qb * w.pooled_stride;
-            a.aux = w.aux + (size_t)blk * qb * w.pooled_stride;
-            a.pooled_stride = w.pooled_stride;
+            a.bins = w.bins + (size_t)blk * qb * w.bins_stride;
+            a.bins_stride = w.bins_stride;
             a.n_rows = idx->n;
             a.nquads = nquads;
             a.nq_valid = idx->scan_nostore == 1 ? 0 : std::min(qb, B - blk * qb);
-            a.dev_layout = idx->scan_nostore;
+            a.dev_store = idx->scan_nostore == 2 ? 1 : 0;
             a.wgmax = w.wgmax + (size_t)blk * qb * RQ_WGMAX_STRIDE;
             a.wgmax_stride = RQ_WGMAX_STRIDE;
             const bool prof = idx->profile == 1 && idx->ev_used < 16384 && (idx->scan_seq++ % (uint64_t)idx->profile_stride) == 0;
@@ -546,9 +537,9 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             if (fused && cx.fused_pending) {
                 cx.fused_pending = false;
                 HIPCHK(rq_scan_tail_launch(a, cx.fused_tail, cx.fused_B, nt, grid, s));
-            } else if (fused) HIPCHK(rq_scan_launch(a, 2, 1, 1, 4, R, nt, grid, s));
-            else if (qb == 128) HIPCHK(rq_scan_launch(a, 3, 4, 1, 8, R, nt, grid, s));
-            else HIPCHK(rq_scan_launch(a, idx->ring, idx->prefetch, idx->kstage, 4, R, nt, grid, s));
+            } else if (fused) HIPCHK(rq_scan_launch(a, 2, 1, 1, 4, nt, grid, s));
+            else if (qb == 128) HIPCHK(rq_scan_launch(a, 3, 4, 1, 8, nt, grid, s));
+            else HIPCHK(rq_scan_launch(a, idx->ring, idx->prefetch, idx->kstage, 4, nt, grid, s));
             if (prof) { HIPCHK(hipEventRecord(idx->events[idx->ev_used].second, s)); idx->ev_used++; }
         }
         if (fast) {
@@ -560,9 +551,9 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             }
             RqTailArgs ta;
             ta.q = d_q; ta.dim = idx->dim; ta.x = idx->x; ta.rownorm64 = idx->rownorm64; ta.n_rows = idx->n;
-            ta.pooled = w.pooled; ta.aux = w.aux; ta.pooled_stride = w.pooled_stride; ta.nbins = nbins;
+            ta.bins = w.bins; ta.bins_stride = w.bins_stride; ta.nbins = nbins;
             ta.wgmax = w.wgmax; ta.wgmax_stride = RQ_WGMAX_STRIDE; ta.nwg = grid;
-            ta.m = m; ta.R = R; ta.metric = metric; ta.k = k;
+            ta.m = m; ta.metric = metric; ta.k = k;
             ta.eps = idx->eps < 0 ? RQ_EPS_DEFAULT : (float)idx->eps;
             ta.max_row_norm = (float)(idx->max_row_norm * (1.0 + 1e-6)); ta.row_offset = idx->row_offset;
             ta.cand = w.cand; ta.rowcount = w.rowcount; ta.done = w.done; ta.ovf = w.ovf;
@@ -591,11 +582,11 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             if (piped) { HIPCHK(hipEventRecord(cx.ev_tail[par], cx.tail)); cx.tail_pending[par] = true; }
             return RQ_OK;
         }
-        HIPCHK(rq_select_bins_launch(w.pooled, w.pooled_stride, nbins, B, m, w.binkeys, s));
+        HIPCHK(rq_select_bins_launch(w.bins, w.bins_stride, nbins, B, m, w.binkeys, s));
     }
     RqRescoreArgs ra;
     ra.x = idx->x; ra.q32 = w.q32; ra.qnorm64 = w.qn; ra.rownorm64 = idx->rownorm64;
-    ra.binkeys = exact ? nullptr : w.binkeys; ra.binkeys_stride = m; ra.nb = nb; ra.R = R; ra.metric = metric;
+    ra.binkeys = exact ? nullptr : w.binkeys; ra.binkeys_stride = m; ra.nb = nb; ra.metric = metric;
     ra.n_rows = idx->n; ra.cand = w.cand;
     HIPCHK(rq_rescore_launch(ra, B, s));
     RqFinalArgs fa;
@@ -766,13 +757,13 @@ extern "C" int64_t rq_debug_pooled(rq_index* idx, void* stream, int query, float
     if (!idx || !out || query < 0) return set_err(RQ_EINVAL, "bad arguments");
     if (int r = use_device(idx)) return r;
     auto it = idx->ctx.find((hipStream_t)stream);
-    if (it == idx->ctx.end() || !it->second.w[0].pooled || query >= it->second.w[0].bcap) return set_err(RQ_EINVAL, "no search has run on this stream");
+    if (it == idx->ctx.end() || !it->second.w[0].bins || query >= it->second.w[0].bcap) return set_err(RQ_EINVAL, "no search has run on this stream");
     const Workspace& w = it->second.w[0];
-    const int per_quad = 16 / idx->bin_tiles;
-    const int64_t nbins = ((idx->n + 63) / 64) * per_quad;
+    const int64_t nbins = (idx->n + 63) / 64;
     const int64_t n = std::min(nbins, max_bins);
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(out, w.pooled + (size_t)query * w.pooled_stride, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    // field x (the bin's largest approximate score) of every 8-byte record
+    HIPCHK(hipMemcpy2D(out, sizeof(float), w.bins + (size_t)query * w.bins_stride, sizeof(uint2), sizeof(float), (size_t)n, hipMemcpyDeviceToHost));
     return n;
 }
 

@@ -6,7 +6,7 @@
 // Vocabulary
 //   row      one passage vector of the corpus (fp16, DPAD elements, zero padded)
 //   quad     64 consecutive rows = 4 tiles of 16 rows; the scan kernel's work unit
-//   bin      4*R rows of one quad whose maximum approximate score the scan kernel keeps
+//   bin      = quad: the 64 rows whose largest / second-largest approximate score and arg-max the scan keeps
 //   key      64-bit sortable (score, index) pair: larger key = better rank
 #pragma once
 #include <hip/hip_runtime.h>
@@ -55,17 +55,9 @@ __host__ __device__ static inline float rq_aux_second(uint32_t w) {
     return f;
 }
 
-// Rows of bin `bin` for bins of 4*R rows (see rq_scan.hip for why bins look like this):
-//   per_quad = 16 / R bins per quad; inside a quad bin = kg * (4/R) + u,
-//   rows = quad*64 + 16*(u*R + tt) + 4*kg + i   for tt < R, i < 4.
-__host__ __device__ static inline int64_t rq_bin_row(int64_t bin, int R, int j /* 0 .. 4R-1 */) {
-    const int per_quad = 16 / R, per_kg = 4 / R;
-    const int64_t quad = bin / per_quad;
-    const int rem = (int)(bin % per_quad);
-    const int kg = rem / per_kg, u = rem % per_kg;
-    const int tt = j >> 2, i = j & 3;
-    return quad * 64 + 16 * (u * R + tt) + 4 * kg + i;
-}
+// One record per (query, bin) written by the scan: x = fp32 bits of the bin's largest approximate score,
+// y = [31:16] second-largest score rounded UP to 16 bits | [5:0] row (0..63) of the largest inside the bin.
+#define RQ_BIN_ROWS 64
 
 #ifdef __HIPCC__
 __device__ __forceinline__ double rq_wave_sum(double v) {

@@ -7,19 +7,18 @@ struct RqScanArgs {
     const void* x;            // fp16 corpus shard [rows_padded][768], rows_padded % 64 == 0, pad rows zero
     const float* row_scale;   // [rows_padded] 1/||row|| (cosine) or 1.0 (inner product); pad entries 0
     const _Float16* qh;       // [QB][768] unit-norm fp16 queries of this block (QB = 64 or 128), unused slots zero
-    float* pooled;            // [QB][pooled_stride] per-bin maxima of the approximate score
-    uint32_t* aux;            // [QB][pooled_stride] per bin: second-largest score (16-bit upper bound) | arg-max position
-    int64_t pooled_stride;    // floats per query row, >= nquads * 16 / R
+    uint2* bins;              // [QB][bins_stride] per (query, quad) record, see rq_device.h
+    int64_t bins_stride;      // records per query row, >= nquads
     int64_t n_rows;           // valid rows of the shard
     int nquads;               // ceil(n_rows / 64)
     int nq_valid;             // queries of this block that are real (<= QB)
     float* wgmax;             // [QB][wgmax_stride] best pooled value per (query, scan workgroup)
     int wgmax_stride;         // >= grid
-    int dev_layout;           // timing experiments only (0 = normal): 2 = each wave writes its bins of a quad as one 256 B run
+    int dev_store;            // timing experiments: 1 = plain (write-back) stores of the bin records instead of non-temporal ones
 };
 #define RQ_WGMAX_STRIDE 1024   // scan grids never exceed this many workgroups
 
-hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int ks, int qw, int R, bool nt, int grid, hipStream_t stream);
+hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int ks, int qw, bool nt, int grid, hipStream_t stream);
 
 // Row statistics at add time: row_norm64[i] = sqrt(sum x^2) in fp64, row_scale[i] = (float)(1/norm) or 0.
 hipError_t rq_rownorm_launch(const void* x, int64_t row_begin, int64_t row_end, double* norm64, hipStream_t stream);
@@ -32,8 +31,8 @@ hipError_t rq_pad_f16_launch(const void* src, int dim, int64_t n, void* dst_rows
 hipError_t rq_prep_queries_launch(const float* q, int dim, int B, int Bpad, _Float16* qh, float* q32pad, double* qnorm64,
                                   hipStream_t stream);
 
-// Pass 2: per query, the m best bins of pooled[q][0..nbins) as sorted keys (score desc, bin asc); 0-padded.
-hipError_t rq_select_bins_launch(const float* pooled, int64_t pooled_stride, int64_t nbins, int B, int m,
+// Pass 2: per query, the m best bins of bins[q][0..nbins) as sorted keys (score desc, bin asc); 0-padded.
+hipError_t rq_select_bins_launch(const uint2* bins, int64_t bins_stride, int64_t nbins, int B, int m,
                                  uint64_t* binkeys, hipStream_t stream);
 
 // Pass 3: exact fp64 re-score of every row of the first nb bins of each query -> candidate keys (score, local row).
@@ -45,10 +44,9 @@ struct RqRescoreArgs {
     const uint64_t* binkeys;   // [B][binkeys_stride]
     int binkeys_stride;
     int nb;                    // bins re-scored per query
-    int R;                     // bin = 4R rows
     int metric;                // 0 cosine, 1 inner product
     int64_t n_rows;
-    uint64_t* cand;            // [B][nb*4R]
+    uint64_t* cand;            // [B][nb*64]
 };
 hipError_t rq_rescore_launch(const RqRescoreArgs& a, int B, hipStream_t stream);
 
@@ -83,9 +81,9 @@ hipError_t rq_final_launch(const RqFinalArgs& a, int B, hipStream_t stream);
 struct RqTailArgs {
     const float* q; int dim;                       // raw fp32 queries [B][dim]
     const void* x; const double* rownorm64; int64_t n_rows;
-    const float* pooled; const uint32_t* aux; int64_t pooled_stride; int64_t nbins;
+    const uint2* bins; int64_t bins_stride; int64_t nbins;
     const float* wgmax; int wgmax_stride; int nwg;
-    int m, R, metric, k;
+    int m, metric, k;
     float eps, max_row_norm;
     int64_t row_offset;
     uint64_t* cand;                                // [B][RQ_CAND_CAP] compact candidate keys
@@ -93,9 +91,12 @@ struct RqTailArgs {
     float* out_scores; int64_t* out_rows; uint64_t* out_keys; int* out_status;
     int stop_after;                                // development: 0 = full kernel, 1..4 = return after phase A..D
 };
-// workgroups [0, scan_grid) run the scan `sa`, the rest the tail `ta` of an EARLIER batch (same bin_tiles R)
+// workgroups [0, scan_grid) run the scan `sa`, the rest the tail `ta` of an EARLIER batch 
 hipError_t rq_scan_tail_launch(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, bool nt, int scan_grid, hipStream_t stream);
 hipError_t rq_tail_launch(const RqTailArgs& a, int B, hipStream_t stream);
+// chunk size rule shared by both launchers: 512-bin chunks while that keeps the grid around a thousand workgroups
+// (enough to spread the hits, few enough to be one dispatch round), else 2048-bin chunks
+static inline bool rq_tail_small_chunks(int64_t nbins, int B) { return ((nbins + 511) / 512) * B <= 1536; }
 
 // Merge G sorted key lists per query (cross-shard): in [B][G*k] -> top-k scores/rows/keys.
 hipError_t rq_merge_keys_launch(const uint64_t* keys, int n_per_query, int B, int k, float* out_scores, int64_t* out_rows,

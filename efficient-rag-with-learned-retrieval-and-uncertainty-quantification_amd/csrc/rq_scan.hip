@@ -1,5 +1,5 @@
 // rq_scan.hip -- pass 1 of the search: stream the fp16 corpus once from HBM, score it against a
-// block of 64 (or 128) queries on the matrix cores, and keep per (query, bin of 4*R rows) the largest
+// block of 64 (or 128) queries on the matrix cores, and keep per (query, bin = quad of 64 rows) the largest
 // approximate score, the second largest and the position of the largest.
 //
 // This is the arithmetic ChromaDB's cosine index performs behind
@@ -17,10 +17,14 @@
 //     the DMA *source* address and on the ds_read_b128 address (LDS image stays lane-linear as
 //     LDS-DMA requires).
 //   * Accumulator layout of the 16x16 MFMA puts the query on the lane and 4 corpus rows in the 4
-//     result registers: max / second max / arg-max of a bin are lane-local (no cross-lane traffic,
-//     no data-dependent control flow in the streaming loop).
-//   * Outputs: pooled[query][bin] fp32 and aux[query][bin] (second max as a 16-bit upper bound |
-//     arg-max position) -- 2 * N/(4R)*64*4 B (2% of the corpus bytes at R=4) -- and wgmax[query][workgroup].
+//     result registers: max / second max / arg-max over the 16 rows a lane sees of a quad are lane-local (no
+//     data-dependent control flow in the streaming loop); the 4 lanes that share a query are merged with two
+//     xor-shuffles per quad.
+//   * Outputs: ONE 8-byte record per (query, quad) -- N/64 * 64 * 8 B = 0.5 % of the corpus bytes -- and
+//     wgmax[query][workgroup].  Writes are what the kernel is sensitive to: with a record per 16 rows (65 MB per
+//     launch, 16-byte pieces) the stores cost 62 of 289 us (measured by switching them off); a workgroup therefore
+//     owns a CONTIGUOUS range of quads, lane group kg keeps the record of quad 4g+kg, and every 4 quads the four
+//     lane groups of a query store 32 contiguous bytes.
 #include "rq_device.h"
 #include "rq_kernels.h"
 #include "rq_tail_body.h"
@@ -36,15 +40,14 @@ __device__ __forceinline__ void rq_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// S: ring depth; R: tiles per bin; NT: non-temporal corpus loads; PF: A fragments read from LDS ahead of
+// S: ring depth; NT: non-temporal corpus loads; PF: A fragments read from LDS ahead of
 // their MFMAs (1, 4, 6 or 12); OCC: waves per SIMD the register allocation must allow; KS: stages per
 // tile (2: a stage is 16 half rows = 12 KiB; 1: a stage is 16 whole rows = 24 KiB contiguous in HBM);
 // QW: waves per workgroup = 16-query groups scored per corpus pass (4: 64 queries, 8: 128 queries).
-template <int S, int R, bool NT, int PF, int KS, int QW>
+template <int S, bool NT, int PF, int KS, int QW>
 __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, const int G) {
     static_assert(S >= 2 && S <= 8, "ring depth");
     static_assert(PF == 1 || PF == 4 || PF == 6 || PF == 12, "fragment prefetch group");
-    static_assert(R == 1 || R == 2 || R == 4, "tiles per bin");
     static_assert(KS == 1 || KS == 2, "stages per tile");
     constexpr int CH = 96 / KS;                    // 16-byte chunks per stage row
     constexpr int STAGE_BYTES = 16 * CH * 16;      // 24576 / KS
@@ -77,14 +80,16 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
     for (int m = 0; m < 4; ++m)
         rbase[m] = (unsigned)(r16 * (CH * 16) + ((kg ^ (r16 & 3)) << 4) + ((m ^ (r16 >> 2)) << 6));
 
-    const int nloc = (a.nquads > b) ? (a.nquads - b + G - 1) / G : 0;
+    // this workgroup's quads: the contiguous range [q_lo, q_lo + nloc)
+    const int q_lo = (int)((int64_t)b * a.nquads / G);
+    const int nloc = (int)((int64_t)(b + 1) * a.nquads / G) - q_lo;
     const int nst = nloc * NSTQ;
     const char* xb = (const char*)a.x;
     char* norm_lds = rq_smem + S * STAGE_BYTES;
 
     auto issue = [&](int st, int slot) {
         const int lq = st / NSTQ, t = (st / KS) & 3, kh = st % KS;
-        const int64_t quad = (int64_t)b + (int64_t)lq * G;
+        const int64_t quad = (int64_t)q_lo + lq;
         const char* g = xb + (quad * RQ_QUAD_ROWS + t * RQ_TILE_ROWS) * (int64_t)(RQ_DPAD * 2) + kh * (RQ_DPAD * 2 / KS);
         char* l = rq_smem + slot * STAGE_BYTES + (wave * DPW) * 1024;
 #pragma unroll
@@ -116,12 +121,26 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
         for (int s = 0; s < 24; ++s) asm volatile("" : "+v"(qf[s]));   // ordinary loads retired before the main loop
     }
 
+    const bool qvalid = 16 * wave + r16 < a.nq_valid;
+    uint2* const myrow = a.bins + (int64_t)(16 * wave + r16) * a.bins_stride;
+    uint2 keep = make_uint2(0u, 0u);   // record of the quad this lane group keeps (quad % 4 == kg)
+    int keep_quad = -1;
+    // The records of a finished group of 4 quads are stored during the FIRST stage of the next quad, right after
+    // that stage's DMA issue, and the following wait lets that one store stay in flight (vmcnt is in order: the
+    // stage data it needs are older).  A store issued at the end of a quad would have to be acknowledged before
+    // the very next stage could start: measured 37 us of 267 per launch even with one store per 4 quads.
+    bool store_pending = false, store_issued = false;   // wave-uniform
+    // Non-temporal stores: with plain (write-back) stores the 8 MB of records cost 19 us per launch (263 -> 245 us,
+    // same box, same run); non-temporal and write-through stores are both indistinguishable from not storing at all.
+    auto store_record = [&](uint2* dst, const uint2 rec) {
+        const uint64_t kv = ((uint64_t)rec.y << 32) | rec.x;
+        if (a.dev_store == 1) *dst = rec;   // timing experiments only
+        else __builtin_nontemporal_store(kv, (uint64_t*)dst);
+    };
     for (int lq = 0; lq < nloc; ++lq) {
-        const int64_t quad = (int64_t)b + (int64_t)lq * G;
-        float binmax[4 / R], bin2[4 / R];   // largest and second-largest approximate score of each bin of this lane
-        int binarg[4 / R];                  // position (0 .. 4R-1) of the largest inside its bin
-#pragma unroll
-        for (int u = 0; u < 4 / R; ++u) { binmax[u] = NEG_INF; bin2[u] = NEG_INF; binarg[u] = 0; }
+        const int quad = q_lo + lq;
+        float m1 = NEG_INF, m2 = NEG_INF;   // largest and second-largest approximate score of the lane's 16 rows
+        int ag = 0;                         // row (0..63) of the largest inside the quad
         const char* nrow = norm_lds + (((lq & 1) * QW + wave) << 8) + kg * 16;
 
 #pragma unroll
@@ -130,10 +149,26 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
 #pragma unroll
             for (int kh = 0; kh < KS; ++kh) {
                 const int st = lq * NSTQ + t * KS + kh;
-                if (st + S - 2 <= nst - 1) rq_wait_vmcnt<VM_KEEP>(); else rq_wait_vmcnt<0>();
+                const bool first_stage = (t == 0 && kh == 0);      // folds: the loops are unrolled
+                const bool second_stage = (t * KS + kh == 1);
+                if (st + S - 2 <= nst - 1) {
+                    if (second_stage && store_issued) rq_wait_vmcnt<VM_KEEP + 1>(); else rq_wait_vmcnt<VM_KEEP>();
+                } else {
+                    rq_wait_vmcnt<0>();
+                }
+                if (second_stage) store_issued = false;
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 if (st + S - 1 < nst) { issue(st + S - 1, islot); islot = (islot + 1 == S) ? 0 : islot + 1; }
+                if (first_stage && store_pending) {
+                    // lane group kg holds quad 4g + kg: the four groups of a query write 32 contiguous bytes
+                    if (qvalid && keep_quad >= 0) {
+                        store_record(myrow + keep_quad, keep);
+                    }
+                    keep_quad = -1;
+                    store_pending = false;
+                    store_issued = true;
+                }
                 const char* sb = rq_smem + cslot * STAGE_BYTES;
                 cslot = (cslot + 1 == S) ? 0 : cslot + 1;
 #pragma unroll
@@ -147,52 +182,42 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
             }
             // tile epilogue: D[row = 4*kg + i][query = r16]
             const rq_float4 nv = *(const rq_float4*)(nrow + t * 64);
-            const int64_t row0 = quad * RQ_QUAD_ROWS + t * RQ_TILE_ROWS + 4 * kg;
-            float m1 = binmax[t / R], m2 = bin2[t / R];
-            int ag = binarg[t / R];
+            const int64_t row0 = (int64_t)quad * RQ_QUAD_ROWS + t * RQ_TILE_ROWS + 4 * kg;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float sc = acc[i] * nv[i];
                 sc = (row0 + i < a.n_rows) ? sc : NEG_INF;
                 const bool gt = sc > m1;                 // false for NaN: NaN scores are dropped
                 m2 = gt ? m1 : fmaxf(m2, sc);            // a tie with m1 makes m2 == m1 (both rows then count as >= m1)
-                ag = gt ? (t % R) * 4 + i : ag;
+                ag = gt ? t * 16 + i : ag;
                 m1 = gt ? sc : m1;
             }
-            binmax[t / R] = m1; bin2[t / R] = m2; binarg[t / R] = ag;
         }
+        // merge the four lane groups that share this query (lanes r16, r16+16, r16+32, r16+48): all end up equal
+        ag += 4 * kg;
 #pragma unroll
-        for (int u = 0; u < 4 / R; ++u) wmax = fmaxf(wmax, binmax[u]);
-        if (16 * wave + r16 < a.nq_valid) {
-            int64_t off = (int64_t)(16 * wave + r16) * a.pooled_stride + quad * (16 / R) + kg * (4 / R);
-            if (a.dev_layout == 2) off = quad * (64 * 16 / R) + (16 * wave + r16) * (16 / R) + kg * (4 / R);
-            float* dst = a.pooled + off;
-            // aux word per bin: [31:16] second-largest score rounded UP to 16 bits (an upper bound), [3:0] arg-max position
-            uint32_t ax[4 / R];
-#pragma unroll
-            for (int u = 0; u < 4 / R; ++u) ax[u] = rq_up16(bin2[u]) | (uint32_t)binarg[u];
-            uint32_t* adst = a.aux + off;
-            if constexpr (R == 4) {
-                dst[0] = binmax[0];
-                adst[0] = ax[0];
-            } else if constexpr (R == 2) {
-                *(float2*)dst = make_float2(binmax[0], binmax[1]);
-                *(uint2*)adst = make_uint2(ax[0], ax[1]);
-            } else {
-                *(float4*)dst = make_float4(binmax[0], binmax[1], binmax[2], binmax[3]);
-                *(uint4*)adst = make_uint4(ax[0], ax[1], ax[2], ax[3]);
-            }
+        for (int off = 16; off <= 32; off <<= 1) {
+            const float o1 = __shfl_xor(m1, off, 64), o2 = __shfl_xor(m2, off, 64);
+            const int oa = __shfl_xor(ag, off, 64);
+            m2 = fmaxf(fminf(m1, o1), fmaxf(m2, o2));
+            const bool take = o1 > m1 || (o1 == m1 && oa < ag);
+            ag = take ? oa : ag;
+            m1 = fmaxf(m1, o1);
         }
+        wmax = fmaxf(wmax, m1);
+        if ((quad & 3) == kg) { keep = make_uint2(__float_as_uint(m1), rq_up16(m2) | (uint32_t)ag); keep_quad = quad; }
+        if ((quad & 3) == 3) store_pending = true;
     }
+    if (qvalid && keep_quad >= 0) store_record(myrow + keep_quad, keep);   // last (possibly partial) group of the range
     // per-workgroup maximum of every query: wgmax[query][workgroup]
     wmax = fmaxf(wmax, __shfl_xor(wmax, 16, 64));
     wmax = fmaxf(wmax, __shfl_xor(wmax, 32, 64));
     if (kg == 0 && 16 * wave + r16 < a.nq_valid) a.wgmax[(int64_t)(16 * wave + r16) * a.wgmax_stride + b] = wmax;
 }
 
-template <int S, int R, bool NT, int PF, int OCC, int KS, int QW>
+template <int S, bool NT, int PF, int OCC, int KS, int QW>
 __global__ __launch_bounds__(64 * QW, OCC) void rq_scan_kernel(RqScanArgs a) {
-    rq_scan_body<S, R, NT, PF, KS, QW>(a, (int)blockIdx.x, (int)gridDim.x);
+    rq_scan_body<S, NT, PF, KS, QW>(a, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Fused launch: workgroups [0, scan_grid) scan the corpus for THIS batch, the others run the tail (threshold, fp64
@@ -200,17 +225,17 @@ __global__ __launch_bounds__(64 * QW, OCC) void rq_scan_kernel(RqScanArgs a) {
 // One stream, no events: the tail's ~20 us hide under the scan, and the scan launches of consecutive batches never
 // overlap each other.  Scan variant: ring 2, whole-row stages, prefetch 1 (51 200 B of LDS, <= 168 VGPRs), so a CU
 // holds 2 scan workgroups + 1 tail workgroup (3 x 51 200 B <= 160 KB; the tail's 13.7 KB are carved from the ring).
-template <int R, bool NT, int NV4>
+template <bool NT, int NV>
 __global__ __launch_bounds__(256, 3) void rq_scan_tail_kernel(RqScanArgs sa, RqTailArgs ta, int scan_grid, int tail_chunks) {
     if ((int)blockIdx.x < scan_grid) {
-        rq_scan_body<2, R, NT, 1, 1, 4>(sa, (int)blockIdx.x, scan_grid);
+        rq_scan_body<2, NT, 1, 1, 4>(sa, (int)blockIdx.x, scan_grid);
     } else {
         const int t = (int)blockIdx.x - scan_grid;
-        rq_tail_body<R, NV4>(ta, t % tail_chunks, t / tail_chunks, tail_chunks, *reinterpret_cast<RqTailLds*>(rq_smem));
+        rq_tail_body<NV>(ta, t % tail_chunks, t / tail_chunks, tail_chunks, *reinterpret_cast<RqTailLds*>(rq_smem));
     }
 }
 
-template <int S, int R, bool NT, int PF, int OCC, int KS, int QW>
+template <int S, bool NT, int PF, int OCC, int KS, int QW>
 static hipError_t rq_scan_launch_t(const RqScanArgs& a, int grid, hipStream_t stream) {
     const size_t lds = (size_t)S * (24576 / KS) + 2 * QW * 256;   // ring + [2 parities][QW waves][64 row scales]
     static unsigned long long attr_done = 0;   // one bit per device
@@ -218,29 +243,24 @@ static hipError_t rq_scan_launch_t(const RqScanArgs& a, int grid, hipStream_t st
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (!((attr_done >> (dev & 63)) & 1ull)) {
-        e = hipFuncSetAttribute((const void*)rq_scan_kernel<S, R, NT, PF, OCC, KS, QW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipFuncSetAttribute((const void*)rq_scan_kernel<S, NT, PF, OCC, KS, QW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done |= 1ull << (dev & 63);
     }
-    hipLaunchKernelGGL((rq_scan_kernel<S, R, NT, PF, OCC, KS, QW>), dim3(grid), dim3(64 * QW), lds, stream, a);
+    hipLaunchKernelGGL((rq_scan_kernel<S, NT, PF, OCC, KS, QW>), dim3(grid), dim3(64 * QW), lds, stream, a);
     return hipGetLastError();
 }
 
 template <int S, int PF, int OCC, int KS, int QW>
-static hipError_t rq_scan_launch_r(const RqScanArgs& a, int R, bool nt, int grid, hipStream_t stream) {
-    switch (R) {
-        case 4: return nt ? rq_scan_launch_t<S, 4, true, PF, OCC, KS, QW>(a, grid, stream) : rq_scan_launch_t<S, 4, false, PF, OCC, KS, QW>(a, grid, stream);
-        case 2: return nt ? rq_scan_launch_t<S, 2, true, PF, OCC, KS, QW>(a, grid, stream) : rq_scan_launch_t<S, 2, false, PF, OCC, KS, QW>(a, grid, stream);
-        case 1: return nt ? rq_scan_launch_t<S, 1, true, PF, OCC, KS, QW>(a, grid, stream) : rq_scan_launch_t<S, 1, false, PF, OCC, KS, QW>(a, grid, stream);
-        default: return hipErrorInvalidValue;
-    }
+static hipError_t rq_scan_launch_r(const RqScanArgs& a, bool nt, int grid, hipStream_t stream) {
+    return nt ? rq_scan_launch_t<S, true, PF, OCC, KS, QW>(a, grid, stream) : rq_scan_launch_t<S, false, PF, OCC, KS, QW>(a, grid, stream);
 }
 
 // (ring S, prefetch PF, stages-per-tile KS, waves QW) combinations that are built; anything else is an error.
 // qw = 4: 64 queries per pass; qw = 8: 128 queries per pass (one workgroup per CU, whole-row stages).
-hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int ks, int qw, int R, bool nt, int grid, hipStream_t stream) {
+hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int ks, int qw, bool nt, int grid, hipStream_t stream) {
     if (grid <= 0) return hipErrorInvalidValue;
-#define RQ_CASE(SS, PP, OO, KK, QQ) if (S == SS && pf == PP && ks == KK && qw == QQ) return rq_scan_launch_r<SS, PP, OO, KK, QQ>(a, R, nt, grid, stream);
+#define RQ_CASE(SS, PP, OO, KK, QQ) if (S == SS && pf == PP && ks == KK && qw == QQ) return rq_scan_launch_r<SS, PP, OO, KK, QQ>(a, nt, grid, stream);
     RQ_CASE(3, 1, 3, 2, 4) RQ_CASE(4, 1, 3, 2, 4)
     RQ_CASE(4, 4, 2, 2, 4) RQ_CASE(6, 4, 2, 2, 4)
     RQ_CASE(5, 6, 2, 2, 4) RQ_CASE(6, 12, 2, 2, 4)
@@ -252,22 +272,22 @@ hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int ks, int qw, in
 
 
 // ---- fused scan(batch i) + tail(batch i-1) -------------------------------------------------------------------
-template <int R, bool NT, int NV4>
+template <bool NT, int NV>
 static hipError_t rq_scan_tail_launch_t(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, int scan_grid, hipStream_t stream) {
     constexpr size_t lds = 2 * 24576 + 2 * 4 * 256;
     static_assert(sizeof(RqTailLds) <= lds, "tail LDS must fit in the scan ring");
-    const int64_t chunks = (ta.nbins + 1024 * NV4 - 1) / (1024 * NV4);
+    const int64_t chunks = (ta.nbins + 512 * NV - 1) / (512 * NV);
     if (chunks < 1 || chunks * tail_B > (1 << 24)) return hipErrorInvalidValue;
     static unsigned long long attr_done = 0;   // one bit per device
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (!((attr_done >> (dev & 63)) & 1ull)) {
-        e = hipFuncSetAttribute((const void*)rq_scan_tail_kernel<R, NT, NV4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipFuncSetAttribute((const void*)rq_scan_tail_kernel<NT, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done |= 1ull << (dev & 63);
     }
-    hipLaunchKernelGGL((rq_scan_tail_kernel<R, NT, NV4>), dim3((unsigned)(scan_grid + chunks * tail_B)), dim3(256), lds, stream, sa, ta,
+    hipLaunchKernelGGL((rq_scan_tail_kernel<NT, NV>), dim3((unsigned)(scan_grid + chunks * tail_B)), dim3(256), lds, stream, sa, ta,
                        scan_grid, (int)chunks);
     return hipGetLastError();
 }
@@ -275,13 +295,7 @@ static hipError_t rq_scan_tail_launch_t(const RqScanArgs& sa, const RqTailArgs& 
 hipError_t rq_scan_tail_launch(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, bool nt, int scan_grid, hipStream_t stream) {
     if (scan_grid <= 0 || tail_B < 1) return hipErrorInvalidValue;
     if (ta.m < 1 || ta.m > RQ_FAST_MAX_M || ta.k < 1 || ta.k > RQ_FAST_MAX_K) return hipErrorInvalidValue;
-    const bool nv1 = ((ta.nbins + 1023) / 1024) * tail_B <= 1536;   // same rule as rq_tail_launch
-#define RQ_FCASE(RR) \
-    if (ta.R == RR) { \
-        if (nt) return nv1 ? rq_scan_tail_launch_t<RR, true, 1>(sa, ta, tail_B, scan_grid, stream) : rq_scan_tail_launch_t<RR, true, 4>(sa, ta, tail_B, scan_grid, stream); \
-        return nv1 ? rq_scan_tail_launch_t<RR, false, 1>(sa, ta, tail_B, scan_grid, stream) : rq_scan_tail_launch_t<RR, false, 4>(sa, ta, tail_B, scan_grid, stream); \
-    }
-    RQ_FCASE(4) RQ_FCASE(2) RQ_FCASE(1)
-#undef RQ_FCASE
-    return hipErrorInvalidValue;
+    const bool nv1 = rq_tail_small_chunks(ta.nbins, tail_B);   // same rule as rq_tail_launch
+    if (nt) return nv1 ? rq_scan_tail_launch_t<true, 1>(sa, ta, tail_B, scan_grid, stream) : rq_scan_tail_launch_t<true, 4>(sa, ta, tail_B, scan_grid, stream);
+    return nv1 ? rq_scan_tail_launch_t<false, 1>(sa, ta, tail_B, scan_grid, stream) : rq_scan_tail_launch_t<false, 4>(sa, ta, tail_B, scan_grid, stream);
 }

@@ -210,19 +210,19 @@ __device__ int rq_wg_topm(KeyAt keyat, int64_t n, int m, uint64_t* list, int* cn
 }
 
 // ---- pass 2 -------------------------------------------------------------------------------
-__global__ __launch_bounds__(RQ_SEL_THREADS) void rq_select_bins_kernel(const float* pooled, int64_t stride, int64_t nbins, int m,
+__global__ __launch_bounds__(RQ_SEL_THREADS) void rq_select_bins_kernel(const uint2* bins, int64_t stride, int64_t nbins, int m,
                                                                        uint64_t* binkeys) {
     __shared__ uint64_t list[RQ_SEL_L];
     __shared__ int cnt;
     const int q = blockIdx.x;
-    const float* p = pooled + (int64_t)q * stride;
-    const int have = rq_wg_topm([&](int64_t i) { return rq_make_key(rq_sanitize(p[i]), (uint32_t)i); }, nbins, m, list, &cnt);
+    const uint2* p = bins + (int64_t)q * stride;
+    const int have = rq_wg_topm([&](int64_t i) { return rq_make_key(rq_sanitize(__uint_as_float(p[i].x)), (uint32_t)i); }, nbins, m, list, &cnt);
     for (int j = threadIdx.x; j < m; j += RQ_SEL_THREADS) binkeys[(int64_t)q * m + j] = j < have ? list[j] : 0;
 }
-hipError_t rq_select_bins_launch(const float* pooled, int64_t pooled_stride, int64_t nbins, int B, int m, uint64_t* binkeys,
+hipError_t rq_select_bins_launch(const uint2* bins, int64_t bins_stride, int64_t nbins, int B, int m, uint64_t* binkeys,
                                  hipStream_t stream) {
     if (m < 1 || m > RQ_SEL_L - RQ_SEL_THREADS) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(rq_select_bins_kernel, dim3(B), dim3(RQ_SEL_THREADS), 0, stream, pooled, pooled_stride, nbins, m, binkeys);
+    hipLaunchKernelGGL(rq_select_bins_kernel, dim3(B), dim3(RQ_SEL_THREADS), 0, stream, bins, bins_stride, nbins, m, binkeys);
     return hipGetLastError();
 }
 
@@ -231,7 +231,7 @@ hipError_t rq_select_bins_launch(const float* pooled, int64_t pooled_stride, int
 __global__ __launch_bounds__(256) void rq_rescore_kernel(RqRescoreArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = blockIdx.y, slot = blockIdx.x;
-    const int binrows = 4 * a.R;
+    constexpr int binrows = RQ_BIN_ROWS;
     uint64_t* out = a.cand + ((int64_t)q * a.nb + slot) * binrows;
     int64_t bin = slot;   // exact mode (binkeys == nullptr): every bin of the shard is re-scored
     if (a.binkeys) {
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void rq_rescore_kernel(RqRescoreArgs a) {
     const double qn = a.qnorm64[q];
     const char* xb = (const char*)a.x;
     for (int j = wave; j < binrows; j += 4) {
-        const int64_t row = rq_bin_row(bin, a.R, j);
+        const int64_t row = bin * RQ_BIN_ROWS + j;
         if (row >= a.n_rows) { if (lane == 0) out[j] = 0; continue; }
         const char* r = xb + row * (RQ_DPAD * 2);
         double dot = 0.0;
@@ -322,8 +322,7 @@ __global__ __launch_bounds__(RQ_SEL_THREADS) void rq_final_kernel(RqFinalArgs a)
                 ok = ((float)bound < sk) ? 1 : 0;
                 if (qn == 0.0) {
                     // every score is 0: the answer is rows 0..k-1, present iff whole leading quads were re-scored
-                    const int per_quad = 16 / (a.ncand / a.nb / 4);
-                    ok = (kk <= (int64_t)(a.nb / per_quad) * 64) ? 1 : 0;
+                    ok = (kk <= (int64_t)a.nb * RQ_BIN_ROWS) ? 1 : 0;
                 }
             }
         }

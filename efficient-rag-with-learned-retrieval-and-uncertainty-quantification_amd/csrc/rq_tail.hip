@@ -1,12 +1,12 @@
 // rq_tail.hip -- everything after the corpus scan in ONE launch (the common case: <= 128 bins wanted, k <= 128).
 //
-// grid (chunks of 1024*NV4 bins, B queries), 256 threads.  Each workgroup
+// grid (chunks of 512*NV bins, B queries), 256 threads.  Each workgroup
 //   A. derives the threshold T = m-th largest partition maximum (partitions = groups of the scan's per-workgroup
 //      maxima; valid because distinct scan workgroups own distinct bins, so at least m bins reach T) with a
 //      20-bit ballot radix select in wave 0,
 //   B. finds the bins of its chunk with pooled >= T and turns them into ROW JOBS: the bin's arg-max row alone when
 //      the bin's second-largest approximate score (aux word, 16-bit upper bound) is below T -- the usual case --
-//      or all 4R rows of the bin otherwise,
+//      or all 64 rows of the bin otherwise,
 //   C. re-scores the job rows exactly in fp64 (16 lanes per row, 8 rows of loads in flight per wave) and appends the
 //      (score, row) keys to the query's compact candidate list with 8-byte write-through (sc1) stores,
 //   D. publishes: every wave drains vmcnt, workgroup barrier, ONE lane draws a ticket (agent-scope atomic add).  The
@@ -20,29 +20,21 @@
 #include "rq_kernels.h"
 #include "rq_tail_body.h"
 
-template <int R, int NV4>
+template <int NV>
 __global__ __launch_bounds__(256) void rq_tail_kernel(RqTailArgs a) {
     __shared__ RqTailLds lds;
-    rq_tail_body<R, NV4>(a, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, lds);
+    rq_tail_body<NV>(a, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, lds);
 }
 
-template <int NV4>
+template <int NV>
 static hipError_t rq_tail_launch_nv(const RqTailArgs& a, int B, hipStream_t stream) {
-    const int64_t chunks = (a.nbins + 1024 * NV4 - 1) / (1024 * NV4);
+    const int64_t chunks = (a.nbins + 512 * NV - 1) / (512 * NV);
     if (chunks < 1 || chunks > 65535) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)chunks, B);
-    switch (a.R) {
-        case 4: hipLaunchKernelGGL((rq_tail_kernel<4, NV4>), grid, dim3(256), 0, stream, a); break;
-        case 2: hipLaunchKernelGGL((rq_tail_kernel<2, NV4>), grid, dim3(256), 0, stream, a); break;
-        case 1: hipLaunchKernelGGL((rq_tail_kernel<1, NV4>), grid, dim3(256), 0, stream, a); break;
-        default: return hipErrorInvalidValue;
-    }
+    hipLaunchKernelGGL((rq_tail_kernel<NV>), dim3((unsigned)chunks, B), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
 hipError_t rq_tail_launch(const RqTailArgs& a, int B, hipStream_t stream) {
     if (a.m < 1 || a.m > RQ_FAST_MAX_M || a.k < 1 || a.k > RQ_FAST_MAX_K) return hipErrorInvalidValue;
-    // about a thousand workgroups: enough to spread the hits, few enough to be one dispatch round
-    const int64_t wgs1 = ((a.nbins + 1023) / 1024) * B;
-    return wgs1 <= 1536 ? rq_tail_launch_nv<1>(a, B, stream) : rq_tail_launch_nv<4>(a, B, stream);
+    return rq_tail_small_chunks(a.nbins, B) ? rq_tail_launch_nv<1>(a, B, stream) : rq_tail_launch_nv<4>(a, B, stream);
 }

@@ -15,13 +15,13 @@ struct __attribute__((aligned(16))) RqTailLds {
     float thr_s;
     int nhit_s, njob_s, base_s, last_s, total_s, ovf_s;
     int hits[RQ_TAIL_HITCAP];
-    int jobs[RQ_TAIL_JOBCAP];     // (hit << 4) | position of the row inside its bin
+    int jobs[RQ_TAIL_JOBCAP];     // (hit << 6) | position of the row inside its bin
     RqFinalLds flds;
 };
 
 // One tail workgroup: chunk `chunk` (of `nchunks`) of query `q`.  256 threads.
-// NV4: float4 loads of pooled values per thread (chunk = 1024 * NV4 bins per workgroup)
-template <int R, int NV4>
+// NV: 16-byte loads (two bin records each) per thread: chunk = 512 * NV bins per workgroup
+template <int NV>
 __device__ __forceinline__ void rq_tail_body(const RqTailArgs& a, const int chunk, const int q, const int nchunks, RqTailLds& L) {
     float* const qs = L.qs;
     double* const qpart = L.qpart;
@@ -31,17 +31,17 @@ __device__ __forceinline__ void rq_tail_body(const RqTailArgs& a, const int chun
     int &nhit_s = L.nhit_s, &njob_s = L.njob_s, &base_s = L.base_s, &last_s = L.last_s, &total_s = L.total_s, &ovf_s = L.ovf_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float NEG_INF = -__builtin_huge_valf();
-    constexpr int binrows = 4 * R;
-    constexpr int CHUNK = 1024 * NV4;
+    constexpr int binrows = RQ_BIN_ROWS;
+    constexpr int CHUNK = 512 * NV;
 
-    // ---- independent loads first: this chunk of pooled values, the query (-> LDS), (wave 0) the partition maxima
-    const float* p = a.pooled + (int64_t)q * a.pooled_stride;
-    const int64_t cbase = (int64_t)chunk * CHUNK + tid * 4;
-    float4 v4[NV4];
+    // ---- independent loads first: this chunk of bin records, the query (-> LDS), (wave 0) the partition maxima
+    const uint2* p = a.bins + (int64_t)q * a.bins_stride;
+    const int64_t cbase = (int64_t)chunk * CHUNK + tid * 2;
+    uint4 v4[NV];
 #pragma unroll
-    for (int u = 0; u < NV4; ++u) {
-        const int64_t i = cbase + (int64_t)u * 1024;
-        v4[u] = (i < a.pooled_stride) ? *(const float4*)(p + i) : make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
+    for (int u = 0; u < NV; ++u) {
+        const int64_t i = cbase + (int64_t)u * 512;
+        v4[u] = (i < a.bins_stride) ? *(const uint4*)(p + i) : make_uint4(0u, 0u, 0u, 0u);   // bins_stride is even
     }
     float qmine[3];
     {
@@ -90,23 +90,22 @@ __device__ __forceinline__ void rq_tail_body(const RqTailArgs& a, const int chun
 
     // ---- B. bins of this chunk that reach the threshold -> row jobs
     {
-        const uint32_t* ax = a.aux + (int64_t)q * a.pooled_stride;
 #pragma unroll
-        for (int u = 0; u < NV4; ++u) {
-            const float xs[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
+        for (int u = 0; u < NV; ++u) {
+            const uint32_t px[2] = {v4[u].x, v4[u].z}, ax[2] = {v4[u].y, v4[u].w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int64_t i = cbase + (int64_t)u * 1024 + e;
-                if (i < a.nbins && xs[e] >= T) {
+            for (int e = 0; e < 2; ++e) {
+                const int64_t i = cbase + (int64_t)u * 512 + e;
+                if (i < a.nbins && __uint_as_float(px[e]) >= T) {
                     const int h = atomicAdd(&nhit_s, 1);
                     if (h < RQ_TAIL_HITCAP) {
                         hits[h] = (int)i;
-                        const uint32_t w = ax[i];
+                        const uint32_t w = ax[e];
                         const bool whole = rq_aux_second(w) >= T;          // a second row of the bin may reach T too
                         const int nj = whole ? binrows : 1;
                         const int j0 = atomicAdd(&njob_s, nj);
                         for (int j = 0; j < nj; ++j)
-                            if (j0 + j < RQ_TAIL_JOBCAP) jobs[j0 + j] = (h << 4) | (whole ? j : (int)(w & 15u));
+                            if (j0 + j < RQ_TAIL_JOBCAP) jobs[j0 + j] = (h << 6) | (whole ? j : (int)(w & 63u));
                     }
                 }
             }
@@ -156,7 +155,7 @@ __device__ __forceinline__ void rq_tail_body(const RqTailArgs& a, const int chun
                 const bool live = jb < njob;
                 const int job = jobs[live ? jb : 0];
                 pos[u] = (live && base + jb < RQ_CAND_CAP) ? base + jb : -1;   // -1: nothing stored (padding or list full)
-                rows[u] = rq_bin_row((int64_t)hits[job >> 4], R, job & 15);
+                rows[u] = (int64_t)hits[job >> 6] * RQ_BIN_ROWS + (job & 63);
                 const int64_t rr = rows[u] < a.n_rows ? rows[u] : 0;
                 rn[u] = a.rownorm64[rr];
                 const char* r = xb + rr * (RQ_DPAD * 2) + sub * 16;

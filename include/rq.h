@@ -103,7 +103,6 @@ int rq_merge_keys_device(const uint64_t* d_keys_in, int n_per_query, int B, int 
 
 /* Tuning / test hooks: "kstage" (1: an LDS stage holds whole rows, 2: half rows), "ring" (LDS stages 2..6; the
  * (kstage, ring, prefetch) triples built are listed in csrc/rq_scan.hip, others fail with RQ_EHIP at search time),
- * "bin_tiles" (1,2,4: bin = 4*bin_tiles rows),
  * "wg_per_cu", "nt" (non-temporal corpus loads: 0, 1, -1 = auto), "slack_bins" (extra bins beyond k, -1 = auto),
  * "eps" (certificate bound, <0 = derived default), "profile" (record HIP events around every scan launch; "profile_stride" n: around every n-th),
  * "prefetch" (LDS fragments read ahead of their MFMAs: 1, 4, 6, 12), "fast_tail" (0 = generic sorted tail),
@@ -128,7 +127,7 @@ int rq_save(const rq_index* idx, const char* path);
 rq_index* rq_load(const char* path, int n_devices, const int* device_ids);
 
 /* Test hook: copy the scan's approximate per-bin maxima of query `query` of the LAST search enqueued on `stream`
- * (bin b of 4*bin_tiles rows, see csrc/rq_device.h rq_bin_row) to the host.  Returns the number of bins copied. */
+ * (bin b = rows 64 b .. 64 b + 63) to the host.  Returns the number of bins copied. */
 int64_t rq_debug_pooled(rq_index* idx, void* stream, int query, float* out, int64_t max_bins);
 
 /* Measurement hook: GB/s of a plain streaming read (16-byte loads, nothing else) of the stored shard, averaged over
