@@ -84,9 +84,9 @@ struct StreamCtx {
     int fused_B = 0;
 };
 
-// Default scan variant: whole-row stages (kstage 1), ring of 2, one LDS fragment ahead (prefetch 1, <= 168 VGPRs),
-// 2 workgroups per CU.  All variants stream at the same 6.2 TB/s; this one leaves room on every SIMD
-// (2 x 168 + 168 <= 512 VGPRs) for a tail workgroup of another stream to be resident beside the scan.
+// Default scan variant: half-row stages (kstage 2), ring of 3, one LDS fragment ahead (prefetch 1, <= 168 VGPRs),
+// 2 workgroups per CU.  All variants stream at the same rate; this one leaves room on every CU (registers:
+// 2 x 168 + 168 <= 512 VGPRs; LDS: 3 x 53 760 B <= 160 KB) for a tail workgroup to be resident beside the scan.
 struct rq_index {
     int dim = 0, device = 0, cu_count = 256;
     int64_t n = 0, cap = 0, row_offset = 0;
@@ -99,7 +99,7 @@ struct rq_index {
     double max_row_norm = 0.0;
     uint64_t scan_seq = 0;         // scan launches seen while profile = 1 (every profile_stride-th one is timed)
     // options
-    int ring = 2, prefetch = 1, kstage = 1, wide_batch = 1, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, profile_stride = 1, scan_nostore = 0, fast_tail = 1, pipeline = 0, tail_stop = 0;
+    int ring = 3, prefetch = 1, kstage = 2, wide_batch = 1, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, profile_stride = 1, scan_nostore = 0, fast_tail = 1, pipeline = 0, tail_stop = 0;
     double eps = -1.0;
     std::map<hipStream_t, StreamCtx> ctx;
     hipStream_t own_stream = nullptr;
@@ -330,10 +330,11 @@ extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     else if (s == "prefetch") { if (v != 1 && v != 4 && v != 6 && v != 12) return set_err(RQ_EINVAL, "prefetch must be 1, 4, 6 or 12"); idx->prefetch = (int)v; }
     else if (s == "wg_per_cu") { if (v < 1 || v > 8) return set_err(RQ_EINVAL, "wg_per_cu must be 1..8"); idx->wg_per_cu = (int)v; }
     else if (s == "nt") idx->nt = (int)v;
+    else if (s == "cu_count") { if (v < 1 || v > 1024) return set_err(RQ_EINVAL, "cu_count must be 1..1024"); idx->cu_count = (int)v; }   // test hook: shrinks the scan grid
     else if (s == "slack_bins") idx->slack_bins = (int)v;
     else if (s == "eps") idx->eps = v;
     else if (s == "profile") idx->profile = (int)v;
-    else if (s == "scan_nostore") idx->scan_nostore = (int)v;   // timing experiments only: 1 = the scan writes nothing (results invalid), 2 = plain instead of non-temporal record stores
+    else if (s == "scan_nostore") idx->scan_nostore = (int)v;   // timing experiments only: 1 = the scan writes nothing (results invalid)
     else if (s == "profile_stride") { if (v < 1) return set_err(RQ_EINVAL, "profile_stride must be >= 1"); idx->profile_stride = (int)v; }
     else if (s == "fast_tail") idx->fast_tail = (int)v;
     else if (s == "pipeline") { if (v != 0 && v != 1 && v != 2) return set_err(RQ_EINVAL, "pipeline must be 0, 1 or 2"); if (int r = flush_all(idx)) return r; idx->pipeline = (int)v; }
@@ -458,7 +459,8 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     const int binrows = RQ_BIN_ROWS;
     const int nquads = (int)((idx->n + 63) / 64);
     const int64_t nbins = nquads;   // bin = quad
-    const bool exact = nb < 0 || nb >= nbins;
+    // tiny shards (fewer than two bins per wanted bin): the approximate pass cannot narrow anything down
+    const bool exact = nb < 0 || 2 * (int64_t)nb >= nbins;
     if (exact) nb = (int)std::min<int64_t>(nbins, INT32_MAX / 64);
     if (!exact && nb > RQ_NB_MAX) return set_err(RQ_EINVAL, "nb %d too large", nb);
     // queries per corpus pass: 128 (8 waves per workgroup, one workgroup per CU) once a call has more than 64
@@ -521,7 +523,6 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             a.n_rows = idx->n;
             a.nquads = nquads;
             a.nq_valid = idx->scan_nostore == 1 ? 0 : std::min(qb, B - blk * qb);
-            a.dev_store = idx->scan_nostore == 2 ? 1 : 0;
             a.wgmax = w.wgmax + (size_t)blk * qb * RQ_WGMAX_STRIDE;
             a.wgmax_stride = RQ_WGMAX_STRIDE;
             const bool prof = idx->profile == 1 && idx->ev_used < 16384 && (idx->scan_seq++ % (uint64_t)idx->profile_stride) == 0;
@@ -537,7 +538,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             if (fused && cx.fused_pending) {
                 cx.fused_pending = false;
                 HIPCHK(rq_scan_tail_launch(a, cx.fused_tail, cx.fused_B, nt, grid, s));
-            } else if (fused) HIPCHK(rq_scan_launch(a, 2, 1, 1, 4, nt, grid, s));
+            } else if (fused) HIPCHK(rq_scan_launch(a, 3, 1, 2, 4, nt, grid, s));
             else if (qb == 128) HIPCHK(rq_scan_launch(a, 3, 4, 1, 8, nt, grid, s));
             else HIPCHK(rq_scan_launch(a, idx->ring, idx->prefetch, idx->kstage, 4, nt, grid, s));
             if (prof) { HIPCHK(hipEventRecord(idx->events[idx->ev_used].second, s)); idx->ev_used++; }
@@ -762,8 +763,10 @@ extern "C" int64_t rq_debug_pooled(rq_index* idx, void* stream, int query, float
     const int64_t nbins = (idx->n + 63) / 64;
     const int64_t n = std::min(nbins, max_bins);
     HIPCHK(hipDeviceSynchronize());
-    // field x (the bin's largest approximate score) of every 8-byte record
-    HIPCHK(hipMemcpy2D(out, sizeof(float), w.bins + (size_t)query * w.bins_stride, sizeof(uint2), sizeof(float), (size_t)n, hipMemcpyDeviceToHost));
+    // field x of every 8-byte record: the bin's largest approximate score (26 bits, rounded up) | its row
+    std::vector<uint32_t> raw((size_t)n);
+    HIPCHK(hipMemcpy2D(raw.data(), sizeof(uint32_t), w.bins + (size_t)query * w.bins_stride, sizeof(uint2), sizeof(uint32_t), (size_t)n, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n; ++i) out[i] = rq_rec_m1(raw[(size_t)i]);
     return n;
 }
 

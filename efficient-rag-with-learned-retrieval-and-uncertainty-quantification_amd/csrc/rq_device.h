@@ -48,16 +48,29 @@ __host__ __device__ static inline uint32_t rq_up16(float f) {
     __builtin_memcpy(&u, &f, 4);
     return (u & 0x80000000u) ? (u & 0xffff0000u) : ((u + 0xffffu) & 0xffff0000u);
 }
-__host__ __device__ static inline float rq_aux_second(uint32_t w) {
-    const uint32_t u = w & 0xffff0000u;
-    float f;
-    __builtin_memcpy(&f, &u, 4);
-    return f;
-}
-
-// One record per (query, bin) written by the scan: x = fp32 bits of the bin's largest approximate score,
-// y = [31:16] second-largest score rounded UP to 16 bits | [5:0] row (0..63) of the largest inside the bin.
+// One 8-byte record per (query, bin) written by the scan (x, y):
+//   x = [31:6] the bin's largest approximate score m1, fp32 bits rounded UP to 26 bits | [5:0] its row (0..63) in the bin
+//   y = [31:16] c2 = 16-bit order-preserving code of the second-largest score m2 rounded up (rq_code16)
+//       [15:6]  d  = min(c2 - c3, 1023), c3 the same code of the third-largest score m3: m3 <= decode(c2 - d)
+//       [5:0]   row of the second largest
+// Every decoded value is an UPPER bound of the true one, which is all the exactness argument needs.
 #define RQ_BIN_ROWS 64
+#define RQ_STAGE_QUADS 32       // records per query a scan workgroup parks in LDS before it writes them out
+__host__ __device__ static inline uint32_t rq_up26(float f) {
+    uint32_t u;
+    __builtin_memcpy(&u, &f, 4);
+    return (u & 0x80000000u) ? (u & 0xffffffc0u) : ((u + 63u) & 0xffffffc0u);
+}
+__host__ __device__ static inline float rq_rec_m1(uint32_t x) { const uint32_t u = x & 0xffffffc0u; float f; __builtin_memcpy(&f, &u, 4); return f; }
+// 16-bit code of f rounded up to 16 bits: c(a) <= c(b) whenever a <= b; rq_code16_value(rq_code16(f)) >= f
+__host__ __device__ static inline uint32_t rq_code16(float f) {
+    const uint32_t u = rq_up16(f);                                   // low 16 bits are zero
+    return ((u & 0x80000000u) ? ~u : (u | 0x80000000u)) >> 16;
+}
+__host__ __device__ static inline float rq_code16_value(uint32_t c) {
+    const uint32_t k = (c << 16) | ((c & 0x8000u) ? 0u : 0xffffu);   // the mono32 image of a 16-bit-rounded float
+    return rq_unmono32(k);
+}
 
 #ifdef __HIPCC__
 __device__ __forceinline__ double rq_wave_sum(double v) {

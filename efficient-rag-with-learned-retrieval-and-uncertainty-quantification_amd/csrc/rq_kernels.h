@@ -14,7 +14,6 @@ struct RqScanArgs {
     int nq_valid;             // queries of this block that are real (<= QB)
     float* wgmax;             // [QB][wgmax_stride] best pooled value per (query, scan workgroup)
     int wgmax_stride;         // >= grid
-    int dev_store;            // timing experiments: 1 = plain (write-back) stores of the bin records instead of non-temporal ones
 };
 #define RQ_WGMAX_STRIDE 1024   // scan grids never exceed this many workgroups
 

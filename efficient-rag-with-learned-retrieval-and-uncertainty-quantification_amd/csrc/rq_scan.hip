@@ -20,11 +20,11 @@
 //     result registers: max / second max / arg-max over the 16 rows a lane sees of a quad are lane-local (no
 //     data-dependent control flow in the streaming loop); the 4 lanes that share a query are merged with two
 //     xor-shuffles per quad.
-//   * Outputs: ONE 8-byte record per (query, quad) -- N/64 * 64 * 8 B = 0.5 % of the corpus bytes -- and
+//   * Outputs: ONE 8-byte record per (query, quad) -- largest score, upper bounds of the second and third largest,
+//     rows of the largest two (rq_device.h); N/64 * 64 * 8 B = 0.5 % of the corpus bytes -- and
 //     wgmax[query][workgroup].  Writes are what the kernel is sensitive to: with a record per 16 rows (65 MB per
 //     launch, 16-byte pieces) the stores cost 62 of 289 us (measured by switching them off); a workgroup therefore
-//     owns a CONTIGUOUS range of quads, lane group kg keeps the record of quad 4g+kg, and every 4 quads the four
-//     lane groups of a query store 32 contiguous bytes.
+//     owns a CONTIGUOUS range of quads and parks its records in LDS until the range is done (see `flush`).
 #include "rq_device.h"
 #include "rq_kernels.h"
 #include "rq_tail_body.h"
@@ -74,18 +74,20 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
         voff[i] = (unsigned)(r * (RQ_DPAD * 2) + ((cp ^ r) << 4));
     }
     // ---- per-lane LDS read offsets: logical chunk 4*s + kg of row r16 sits at chunk ((4s+kg) ^ r16)
-    //      = 4*(s ^ (r16>>2)) + (kg ^ (r16&3));  split s = (s & ~3) | (s & 3): 4 lane bases + immediates
-    unsigned rbase[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-        rbase[m] = (unsigned)(r16 * (CH * 16) + ((kg ^ (r16 & 3)) << 4) + ((m ^ (r16 >> 2)) << 6));
+    //      = 4*(s ^ (r16>>2)) + (kg ^ (r16&3));  split s = (s & ~3) | (s & 3): the high part is an immediate, the low
+    //      part m = s & 3 enters as ((m ^ (r16>>2)) << 6) = (m << 6) ^ ((r16>>2) << 6).  The row base r16 * CH * 16 is a
+    //      multiple of 256, so bits 6..7 of rbase0 hold only that term and rbase(m) = rbase0 ^ (m << 6): one VGPR and
+    //      a v_xor per read instead of four VGPRs (the register budget is 168, see rq_scan_tail_kernel).
+    static_assert((CH * 16) % 256 == 0, "row pitch must keep bits 6..7 free");
+    const unsigned rbase0 = (unsigned)(r16 * (CH * 16) + ((kg ^ (r16 & 3)) << 4) + ((r16 >> 2) << 6));
 
     // this workgroup's quads: the contiguous range [q_lo, q_lo + nloc)
     const int q_lo = (int)((int64_t)b * a.nquads / G);
     const int nloc = (int)((int64_t)(b + 1) * a.nquads / G) - q_lo;
     const int nst = nloc * NSTQ;
     const char* xb = (const char*)a.x;
-    char* norm_lds = rq_smem + S * STAGE_BYTES;
+    char* norm_lds = rq_smem + S * STAGE_BYTES;                 // [2 parities][64 row scales], shared by the waves
+    uint2* const stg = (uint2*)(norm_lds + 512);                // [16 * QW queries][RQ_STAGE_QUADS] finished records
 
     auto issue = [&](int st, int slot) {
         const int lq = st / NSTQ, t = (st / KS) & 3, kh = st % KS;
@@ -95,9 +97,9 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
 #pragma unroll
         for (int i = 0; i < DPW; ++i)
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(g + voff[i]), (lds_ptr_t)(l + i * 1024), 16, 0, AUX);
-        if ((st % NSTQ) == 0) {   // row scales of the quad, one private copy per wave (256 B)
-            const float* ns = a.row_scale + quad * RQ_QUAD_ROWS + lane;
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)ns, (lds_ptr_t)(norm_lds + (((lq & 1) * QW + wave) << 8)), 4, 0, 0);
+        if ((st % NSTQ) == 0 && wave == 0) {   // row scales of the quad (256 B): wave 0's counted wait + the stage barrier
+            const float* ns = a.row_scale + quad * RQ_QUAD_ROWS + lane;   // make them visible to all waves
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)ns, (lds_ptr_t)(norm_lds + ((lq & 1) << 8)), 4, 0, 0);
         }
     };
 
@@ -121,27 +123,26 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
         for (int s = 0; s < 24; ++s) asm volatile("" : "+v"(qf[s]));   // ordinary loads retired before the main loop
     }
 
-    const bool qvalid = 16 * wave + r16 < a.nq_valid;
-    uint2* const myrow = a.bins + (int64_t)(16 * wave + r16) * a.bins_stride;
-    uint2 keep = make_uint2(0u, 0u);   // record of the quad this lane group keeps (quad % 4 == kg)
-    int keep_quad = -1;
-    // The records of a finished group of 4 quads are stored during the FIRST stage of the next quad, right after
-    // that stage's DMA issue, and the following wait lets that one store stay in flight (vmcnt is in order: the
-    // stage data it needs are older).  A store issued at the end of a quad would have to be acknowledged before
-    // the very next stage could start: measured 37 us of 267 per launch even with one store per 4 quads.
-    bool store_pending = false, store_issued = false;   // wave-uniform
-    // Non-temporal stores: with plain (write-back) stores the 8 MB of records cost 19 us per launch (263 -> 245 us,
-    // same box, same run); non-temporal and write-through stores are both indistinguishable from not storing at all.
-    auto store_record = [&](uint2* dst, const uint2 rec) {
-        const uint64_t kv = ((uint64_t)rec.y << 32) | rec.x;
-        if (a.dev_store == 1) *dst = rec;   // timing experiments only
-        else __builtin_nontemporal_store(kv, (uint64_t*)dst);
+    // Finished records wait in LDS and leave in ONE burst per RQ_STAGE_QUADS quads (normally once, at the end of the
+    // workgroup's range).  Stores inside the streaming loop are what this kernel is sensitive to: every store
+    // instruction that touches 16 different lines holds up the CU's vector-memory address pipe for ~500 cycles
+    // (TCP_TCP_TA_ADDR_STALL / _DATA_STALL counters), and the DMA loads queue behind it.  Measured per launch (same
+    // box, same run; no store at all = 232 us): a record per 16 rows +62 us, a 16-byte record per quad +45 us, an
+    // 8-byte record per quad stored every 4 quads +32 us (non-temporal / write-through / plain alike, any ring depth,
+    // any position inside the stage), every quad +60 us.
+    auto flush = [&](int quad0, int count) {
+        // each wave writes the rows of its own 16 queries: 2 queries x 32 records (256-byte runs) per instruction
+#pragma unroll 1
+        for (int i = 0; i < 8; ++i) {
+            const int ql = 16 * wave + 2 * i + (lane >> 5), j = lane & (RQ_STAGE_QUADS - 1);
+            if (j < count && ql < a.nq_valid) a.bins[(int64_t)ql * a.bins_stride + quad0 + j] = stg[ql * RQ_STAGE_QUADS + j];
+        }
     };
     for (int lq = 0; lq < nloc; ++lq) {
         const int quad = q_lo + lq;
-        float m1 = NEG_INF, m2 = NEG_INF;   // largest and second-largest approximate score of the lane's 16 rows
-        int ag = 0;                         // row (0..63) of the largest inside the quad
-        const char* nrow = norm_lds + (((lq & 1) * QW + wave) << 8) + kg * 16;
+        float m1 = NEG_INF, m2 = NEG_INF, m3 = NEG_INF;   // the three largest approximate scores of the lane's 16 rows
+        uint32_t ap = 0;                                  // rows (0..63) of the largest [7:0] and second largest [15:8]
+        const char* nrow = norm_lds + ((lq & 1) << 8) + kg * 16;
 
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -149,33 +150,17 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
 #pragma unroll
             for (int kh = 0; kh < KS; ++kh) {
                 const int st = lq * NSTQ + t * KS + kh;
-                const bool first_stage = (t == 0 && kh == 0);      // folds: the loops are unrolled
-                const bool second_stage = (t * KS + kh == 1);
-                if (st + S - 2 <= nst - 1) {
-                    if (second_stage && store_issued) rq_wait_vmcnt<VM_KEEP + 1>(); else rq_wait_vmcnt<VM_KEEP>();
-                } else {
-                    rq_wait_vmcnt<0>();
-                }
-                if (second_stage) store_issued = false;
+                if (st + S - 2 <= nst - 1) rq_wait_vmcnt<VM_KEEP>(); else rq_wait_vmcnt<0>();
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 if (st + S - 1 < nst) { issue(st + S - 1, islot); islot = (islot + 1 == S) ? 0 : islot + 1; }
-                if (first_stage && store_pending) {
-                    // lane group kg holds quad 4g + kg: the four groups of a query write 32 contiguous bytes
-                    if (qvalid && keep_quad >= 0) {
-                        store_record(myrow + keep_quad, keep);
-                    }
-                    keep_quad = -1;
-                    store_pending = false;
-                    store_issued = true;
-                }
                 const char* sb = rq_smem + cslot * STAGE_BYTES;
                 cslot = (cslot + 1 == S) ? 0 : cslot + 1;
 #pragma unroll
                 for (int g = 0; g < MF; g += PF) {
                     rq_half8 av[PF];
 #pragma unroll
-                    for (int s = 0; s < PF; ++s) av[s] = *(const rq_half8*)(sb + rbase[(g + s) & 3] + (((g + s) & ~3) << 6));
+                    for (int s = 0; s < PF; ++s) av[s] = *(const rq_half8*)(sb + (rbase0 ^ (unsigned)(((g + s) & 3) << 6)) + (((g + s) & ~3) << 6));
 #pragma unroll
                     for (int s = 0; s < PF; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[s], qf[kh * MF + g + s], acc, 0, 0, 0);
                 }
@@ -187,32 +172,52 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
             for (int i = 0; i < 4; ++i) {
                 float sc = acc[i] * nv[i];
                 sc = (row0 + i < a.n_rows) ? sc : NEG_INF;
-                const bool gt = sc > m1;                 // false for NaN: NaN scores are dropped
-                m2 = gt ? m1 : fmaxf(m2, sc);            // a tie with m1 makes m2 == m1 (both rows then count as >= m1)
-                ag = gt ? t * 16 + i : ag;
-                m1 = gt ? sc : m1;
+                // comparisons are false for NaN: NaN scores are dropped.  Ties count as separate rows: a tie with m1
+                // becomes m2 (with its own position), a tie with m2 becomes m3.
+                const bool gt1 = sc > m1, gt2 = sc > m2;
+                const uint32_t pos = (uint32_t)(t * 16 + i);
+                m3 = gt2 ? m2 : fmaxf(m3, sc);
+                ap = gt1 ? ((ap << 8) | pos) : (gt2 ? ((ap & 0xffu) | (pos << 8)) : ap);
+                m2 = gt1 ? m1 : fmaxf(m2, sc);
+                m1 = gt1 ? sc : m1;
             }
         }
         // merge the four lane groups that share this query (lanes r16, r16+16, r16+32, r16+48): all end up equal
-        ag += 4 * kg;
+        ap = (ap & 0xffffu) + (uint32_t)(4 * kg) * 0x0101u;
+        // merge the sorted triples of the two lists (this lane's and the other lane's): both lanes compute the same
 #pragma unroll
         for (int off = 16; off <= 32; off <<= 1) {
-            const float o1 = __shfl_xor(m1, off, 64), o2 = __shfl_xor(m2, off, 64);
-            const int oa = __shfl_xor(ag, off, 64);
-            m2 = fmaxf(fminf(m1, o1), fmaxf(m2, o2));
-            const bool take = o1 > m1 || (o1 == m1 && oa < ag);
-            ag = take ? oa : ag;
-            m1 = fmaxf(m1, o1);
+            const float o1 = __shfl_xor(m1, off, 64), o2 = __shfl_xor(m2, off, 64), o3 = __shfl_xor(m3, off, 64);
+            const uint32_t op = (uint32_t)__shfl_xor((int)ap, off, 64);
+            // W = the list whose head wins (ties: smaller row), L = the other one
+            const bool ow = o1 > m1 || (o1 == m1 && (op & 0xffu) < (ap & 0xffu));
+            const float w1 = ow ? o1 : m1, w2 = ow ? o2 : m2, w3 = ow ? o3 : m3;
+            const float l1 = ow ? m1 : o1, l2 = ow ? m2 : o2;
+            const uint32_t wp = ow ? op : ap, lp = ow ? ap : op;
+            const bool tl = l1 > w2 || (l1 == w2 && (lp & 0xffu) < (wp >> 8));   // L's head is the second largest
+            m1 = w1;
+            m2 = tl ? l1 : w2;
+            m3 = tl ? fmaxf(w2, l2) : fmaxf(w3, l1);
+            ap = (wp & 0xffu) | (tl ? (lp & 0xffu) << 8 : (wp & 0xff00u));
         }
         wmax = fmaxf(wmax, m1);
-        if ((quad & 3) == kg) { keep = make_uint2(__float_as_uint(m1), rq_up16(m2) | (uint32_t)ag); keep_quad = quad; }
-        if ((quad & 3) == 3) store_pending = true;
+        if (kg == 0) {   // the four lane groups hold the same record
+            const uint32_t c2 = rq_code16(m2), c3 = rq_code16(m3), d = c2 - c3;   // c3 <= c2
+            stg[(16 * wave + r16) * RQ_STAGE_QUADS + (lq & (RQ_STAGE_QUADS - 1))] =
+                make_uint2(rq_up26(m1) | (ap & 63u), (c2 << 16) | ((d < 1023u ? d : 1023u) << 6) | ((ap >> 8) & 63u));
+        }
+        if ((lq & (RQ_STAGE_QUADS - 1)) == RQ_STAGE_QUADS - 1 || lq == nloc - 1)
+            flush(q_lo + (lq & ~(RQ_STAGE_QUADS - 1)), (lq & (RQ_STAGE_QUADS - 1)) + 1);
     }
-    if (qvalid && keep_quad >= 0) store_record(myrow + keep_quad, keep);   // last (possibly partial) group of the range
     // per-workgroup maximum of every query: wgmax[query][workgroup]
     wmax = fmaxf(wmax, __shfl_xor(wmax, 16, 64));
     wmax = fmaxf(wmax, __shfl_xor(wmax, 32, 64));
     if (kg == 0 && 16 * wave + r16 < a.nq_valid) a.wgmax[(int64_t)(16 * wave + r16) * a.wgmax_stride + b] = wmax;
+}
+
+// ring + [2 parities][64 row scales] + record staging [16 * QW queries][RQ_STAGE_QUADS]
+static constexpr size_t rq_scan_lds_bytes(int S, int KS, int QW) {
+    return (size_t)S * (24576 / KS) + 512 + (size_t)16 * QW * RQ_STAGE_QUADS * 8;
 }
 
 template <int S, bool NT, int PF, int OCC, int KS, int QW>
@@ -223,12 +228,13 @@ __global__ __launch_bounds__(64 * QW, OCC) void rq_scan_kernel(RqScanArgs a) {
 // Fused launch: workgroups [0, scan_grid) scan the corpus for THIS batch, the others run the tail (threshold, fp64
 // re-score, final top-k) of the PREVIOUS batch of the same stream, whose scan finished with the previous launch.
 // One stream, no events: the tail's ~20 us hide under the scan, and the scan launches of consecutive batches never
-// overlap each other.  Scan variant: ring 2, whole-row stages, prefetch 1 (51 200 B of LDS, <= 168 VGPRs), so a CU
-// holds 2 scan workgroups + 1 tail workgroup (3 x 51 200 B <= 160 KB; the tail's 13.7 KB are carved from the ring).
+// overlap each other.  Scan variant: ring of 3 half-row stages, prefetch 1 (36 KB ring + 16.5 KB of record staging =
+// 53 760 B of LDS, <= 168 VGPRs), so a CU holds 2 scan workgroups + 1 tail workgroup (3 x 53 760 B <= 160 KB; the
+// tail's 16 KB are carved from the ring).
 template <bool NT, int NV>
 __global__ __launch_bounds__(256, 3) void rq_scan_tail_kernel(RqScanArgs sa, RqTailArgs ta, int scan_grid, int tail_chunks) {
     if ((int)blockIdx.x < scan_grid) {
-        rq_scan_body<2, NT, 1, 1, 4>(sa, (int)blockIdx.x, scan_grid);
+        rq_scan_body<3, NT, 1, 2, 4>(sa, (int)blockIdx.x, scan_grid);
     } else {
         const int t = (int)blockIdx.x - scan_grid;
         rq_tail_body<NV>(ta, t % tail_chunks, t / tail_chunks, tail_chunks, *reinterpret_cast<RqTailLds*>(rq_smem));
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(256, 3) void rq_scan_tail_kernel(RqScanArgs sa, RqT
 
 template <int S, bool NT, int PF, int OCC, int KS, int QW>
 static hipError_t rq_scan_launch_t(const RqScanArgs& a, int grid, hipStream_t stream) {
-    const size_t lds = (size_t)S * (24576 / KS) + 2 * QW * 256;   // ring + [2 parities][QW waves][64 row scales]
+    const size_t lds = rq_scan_lds_bytes(S, KS, QW);
     static unsigned long long attr_done = 0;   // one bit per device
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -274,8 +280,9 @@ hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int ks, int qw, bo
 // ---- fused scan(batch i) + tail(batch i-1) -------------------------------------------------------------------
 template <bool NT, int NV>
 static hipError_t rq_scan_tail_launch_t(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, int scan_grid, hipStream_t stream) {
-    constexpr size_t lds = 2 * 24576 + 2 * 4 * 256;
-    static_assert(sizeof(RqTailLds) <= lds, "tail LDS must fit in the scan ring");
+    constexpr size_t lds = rq_scan_lds_bytes(3, 2, 4);
+    static_assert(sizeof(RqTailLds) <= lds, "tail LDS must fit in the scan's LDS");
+    static_assert(3 * lds <= 160 * 1024, "2 scan workgroups + 1 tail workgroup per CU");
     const int64_t chunks = (ta.nbins + 512 * NV - 1) / (512 * NV);
     if (chunks < 1 || chunks * tail_B > (1 << 24)) return hipErrorInvalidValue;
     static unsigned long long attr_done = 0;   // one bit per device

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(RQ_SEL_THREADS) void rq_select_bins_kernel(const ui
     __shared__ int cnt;
     const int q = blockIdx.x;
     const uint2* p = bins + (int64_t)q * stride;
-    const int have = rq_wg_topm([&](int64_t i) { return rq_make_key(rq_sanitize(__uint_as_float(p[i].x)), (uint32_t)i); }, nbins, m, list, &cnt);
+    const int have = rq_wg_topm([&](int64_t i) { return rq_make_key(rq_sanitize(rq_rec_m1(p[i].x)), (uint32_t)i); }, nbins, m, list, &cnt);
     for (int j = threadIdx.x; j < m; j += RQ_SEL_THREADS) binkeys[(int64_t)q * m + j] = j < have ? list[j] : 0;
 }
 hipError_t rq_select_bins_launch(const uint2* bins, int64_t bins_stride, int64_t nbins, int B, int m, uint64_t* binkeys,

@@ -5,8 +5,8 @@
 #include "rq_kernels.h"
 #include "rq_final_body.h"
 
-#define RQ_TAIL_HITCAP 64      // candidate bins one workgroup can hold
-#define RQ_TAIL_JOBCAP 512     // row jobs one workgroup can hold
+#define RQ_TAIL_HITCAP 128     // candidate bins one workgroup can hold
+#define RQ_TAIL_JOBCAP 1024    // row jobs one workgroup can hold
 
 // LDS of one tail workgroup (13.7 KB): static in rq_tail_kernel, carved from the scan's ring in the fused kernel.
 struct __attribute__((aligned(16))) RqTailLds {
@@ -37,7 +37,7 @@ __device__ __forceinline__ void rq_tail_body(const RqTailArgs& a, const int chun
     // ---- independent loads first: this chunk of bin records, the query (-> LDS), (wave 0) the partition maxima
     const uint2* p = a.bins + (int64_t)q * a.bins_stride;
     const int64_t cbase = (int64_t)chunk * CHUNK + tid * 2;
-    uint4 v4[NV];
+    uint4 v4[NV];   // two records each
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
         const int64_t i = cbase + (int64_t)u * 512;
@@ -88,24 +88,26 @@ __device__ __forceinline__ void rq_tail_body(const RqTailArgs& a, const int chun
     const float T = thr_s;
     if (a.stop_after == 1) { if (tid == 0 && chunk == 0) a.out_status[q] = (int)T; return; }
 
-    // ---- B. bins of this chunk that reach the threshold -> row jobs
+    // ---- B. bins of this chunk that reach the threshold -> row jobs: the arg-max row alone when the bin's second
+    //      largest score is below T, the two largest when only the third is, all 64 rows otherwise
     {
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
-            const uint32_t px[2] = {v4[u].x, v4[u].z}, ax[2] = {v4[u].y, v4[u].w};
+            const uint32_t rx[2] = {v4[u].x, v4[u].z}, ry[2] = {v4[u].y, v4[u].w};
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int64_t i = cbase + (int64_t)u * 512 + e;
-                if (i < a.nbins && __uint_as_float(px[e]) >= T) {
+                if (i < a.nbins && rq_rec_m1(rx[e]) >= T) {
                     const int h = atomicAdd(&nhit_s, 1);
                     if (h < RQ_TAIL_HITCAP) {
                         hits[h] = (int)i;
-                        const uint32_t w = ax[e];
-                        const bool whole = rq_aux_second(w) >= T;          // a second row of the bin may reach T too
-                        const int nj = whole ? binrows : 1;
+                        const uint32_t c2 = ry[e] >> 16, d = (ry[e] >> 6) & 1023u;
+                        const bool two = rq_code16_value(c2) >= T, whole = two && rq_code16_value(c2 - d) >= T;
+                        const int nj = whole ? binrows : (two ? 2 : 1);
                         const int j0 = atomicAdd(&njob_s, nj);
+                        const int a1 = (int)(rx[e] & 63u), a2 = (int)(ry[e] & 63u);
                         for (int j = 0; j < nj; ++j)
-                            if (j0 + j < RQ_TAIL_JOBCAP) jobs[j0 + j] = (h << 6) | (whole ? j : (int)(w & 63u));
+                            if (j0 + j < RQ_TAIL_JOBCAP) jobs[j0 + j] = (h << 6) | (whole ? j : (j ? a2 : a1));
                     }
                 }
             }

@@ -529,8 +529,9 @@ def test_scan_bin_maxima_within_certificate_eps(n):
     nbins = (n + 63) // 64
     rows = np.arange(nbins)[:, None] * 64 + np.arange(64)[None, :]
     valid = rows < n
-    for wg in (2, 1, 3):                                               # different quad ranges per workgroup
-        idx.set_option("wg_per_cu", wg)
+    for wg, cus in ((2, 256), (1, 256), (3, 256), (1, 7), (2, 3)):     # different quad ranges per workgroup; the small grids
+        idx.set_option("wg_per_cu", wg)                                #   give ranges of more than 32 quads (several LDS flushes)
+        idx.set_option("cu_count", cus)
         idx.search_device(dq, B, 10, 0, sc, rw, None, st, 0)
         torch.cuda.synchronize()
         worst = 0.0

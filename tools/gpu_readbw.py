@@ -30,7 +30,7 @@ for rnd in range(3):
             print(f"round {rnd} read probe wg/cu={wg:2d} nt={nt}: {idx.read_bandwidth(20, nt, wg):7.1f} GB/s", flush=True)
     us = scan_us()
     print(f"round {rnd} scan kernel: {us:6.1f} us = {N * 1536 / us / 1e3:7.1f} GB/s", flush=True)
-    for mode, what in ((1, "WITHOUT its bin-record stores"), (2, "with plain (write-back) record stores")):
+    for mode, what in ((1, "WITHOUT its bin-record stores"),):
         idx.set_option("scan_nostore", mode)
         us = scan_us()
         idx.set_option("scan_nostore", 0)
