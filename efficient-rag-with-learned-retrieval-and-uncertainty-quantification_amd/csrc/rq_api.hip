@@ -454,7 +454,7 @@ static int flush_all(rq_index* idx) {
 // One pass of the pipeline for B queries.  nb < 0: exact scan (every bin re-scored, no corpus scan).
 // may_defer: the caller accepts results that are complete only after rq_search_flush_device ("pipeline" option).
 static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metric, int nb, float* d_scores, int64_t* d_rows,
-                        uint64_t* d_keys, int* d_status, hipStream_t s, bool may_defer = false) {
+                        uint64_t* d_keys, int* d_status, hipStream_t s, bool may_defer = false, bool force_generic = false) {
     if (idx->n == 0) return fill_empty(B, k, d_scores, d_rows, d_keys, d_status, s);
     const int binrows = RQ_BIN_ROWS;
     const int nquads = (int)((idx->n + 63) / 64);
@@ -467,8 +467,8 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     const int qb = (idx->wide_batch && B > 64) ? 128 : 64;
     const int bpad = (B + qb - 1) / qb * qb;
     const int64_t stride = (nbins + 63) / 64 * 64;
-    const int m = nb + 1;
-    const bool fast = !exact && idx->fast_tail && m <= RQ_FAST_MAX_M && k <= RQ_FAST_MAX_K;
+    const int m = nb + 1;   // generic tail: bins re-scored + the first one that is not
+    const bool fast = !exact && !force_generic && idx->fast_tail && k <= RQ_FAST_MAX_K;
     const int64_t ncand = fast ? (int64_t)RQ_CAND_CAP : (int64_t)nb * binrows;
     StreamCtx& cx = idx->ctx[s];
     const bool piped = fast && may_defer && idx->pipeline == 1;
@@ -554,7 +554,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             ta.q = d_q; ta.dim = idx->dim; ta.x = idx->x; ta.rownorm64 = idx->rownorm64; ta.n_rows = idx->n;
             ta.bins = w.bins; ta.bins_stride = w.bins_stride; ta.nbins = nbins;
             ta.wgmax = w.wgmax; ta.wgmax_stride = RQ_WGMAX_STRIDE; ta.nwg = grid;
-            ta.m = m; ta.metric = metric; ta.k = k;
+            ta.m = (int)std::min<int64_t>(k, idx->n); ta.metric = metric; ta.k = k;
             ta.eps = idx->eps < 0 ? RQ_EPS_DEFAULT : (float)idx->eps;
             ta.max_row_norm = (float)(idx->max_row_norm * (1.0 + 1e-6)); ta.row_offset = idx->row_offset;
             ta.cand = w.cand; ta.rowcount = w.rowcount; ta.done = w.done; ta.ovf = w.ovf;
@@ -657,7 +657,8 @@ extern "C" int rq_search_fixup_device(rq_index* idx, const float* d_queries, int
                                   hipMemcpyDeviceToDevice, s));
         if (level == 0) {
             idx->t.widened += nbq;
-            if (int r = run_pipeline(idx, w.fix_q, nbq, k, metric, nb1, w.fix_scores, w.fix_rows, w.fix_keys, w.fix_status, s)) return r;
+            // (the fast tail fails only when its candidate lists overflow: the wider pass uses the generic sorted tail)
+            if (int r = run_pipeline(idx, w.fix_q, nbq, k, metric, nb1, w.fix_scores, w.fix_rows, w.fix_keys, w.fix_status, s, false, true)) return r;
         } else {
             idx->t.exact_scans += nbq;
             // bound the candidate memory: a few queries per exact pass

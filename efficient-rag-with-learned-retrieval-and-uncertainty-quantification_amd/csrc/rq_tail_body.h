@@ -5,8 +5,8 @@
 #include "rq_kernels.h"
 #include "rq_final_body.h"
 
-#define RQ_TAIL_HITCAP 128     // candidate bins one workgroup can hold
-#define RQ_TAIL_JOBCAP 1024    // row jobs one workgroup can hold
+#define RQ_TAIL_HITCAP 256     // candidate bins one workgroup can hold
+#define RQ_TAIL_JOBCAP 2048    // row jobs one workgroup can hold
 
 // LDS of one tail workgroup (13.7 KB): static in rq_tail_kernel, carved from the scan's ring in the fused kernel.
 struct __attribute__((aligned(16))) RqTailLds {
@@ -18,6 +18,8 @@ struct __attribute__((aligned(16))) RqTailLds {
     int jobs[RQ_TAIL_JOBCAP];     // (hit << 6) | position of the row inside its bin
     RqFinalLds flds;
 };
+
+template <int N> struct RqInt { static constexpr int value = N; };
 
 // One tail workgroup: chunk `chunk` (of `nchunks`) of query `q`.  256 threads.
 // NV: 16-byte loads (two bin records each) per thread: chunk = 512 * NV bins per workgroup
@@ -51,38 +53,46 @@ __device__ __forceinline__ void rq_tail_body(const RqTailArgs& a, const int chun
     }
     if (tid == 0) { thr_s = NEG_INF; nhit_s = 0; njob_s = 0; last_s = 0; }
 
-    // ---- A. threshold: ballot radix select (wave 0) of the m-th largest partition maximum, truncated to the
-    //      top 20 key bits (a slightly lower, still valid threshold).  m <= 24: 64 partitions (one per lane),
-    //      else 256 (four per lane): more partitions = tighter threshold when m is large.
+    // ---- A. threshold.  P = the m-th largest partition maximum (m = the k rows wanted; partitions = groups of the
+    //      scan's per-workgroup maxima, distinct workgroups own distinct bins), found by a ballot radix select in
+    //      wave 0 and truncated to the top 20 key bits (a slightly lower value).  At least m rows have an approximate
+    //      score >= P, so the k-th exact score is >= P - eps.  T = P - 2 eps - margin therefore always satisfies the
+    //      certificate T + eps < s_k: the candidate set adapts to how dense the scores are around the k-th one
+    //      (about k + 2 rows on Gaussian data, hundreds inside a tight cluster) instead of failing there.
+    //      64 partitions (one per lane) for m <= 8, 256 for m <= 64, else 512: more partitions = tighter P.
     if (wave == 0) {
         const float* w = a.wgmax + (int64_t)q * a.wgmax_stride;
         uint32_t prefix = 0;
-        if (a.m <= 24) {
-            float v = NEG_INF;
-            for (int j = lane; j < a.nwg; j += 64) v = fmaxf(v, w[j]);
-            const uint32_t key = rq_mono32(v);
-            for (int bit = 31; bit >= 12; --bit) {
-                const uint32_t t = prefix | (1u << bit);
-                if (__popcll(__ballot(key >= t)) >= a.m) prefix = t;   // uniform
-            }
-        } else if (a.m <= 256) {
-            uint32_t key[4];
+        auto select = [&](auto npl_tag) {
+            constexpr int NPL = decltype(npl_tag)::value;   // partitions per lane
+            uint32_t key[NPL];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NPL; ++i) {
                 float v = NEG_INF;
-                for (int j = i * 64 + lane; j < a.nwg; j += 256) v = fmaxf(v, w[j]);
+                for (int j = i * 64 + lane; j < a.nwg; j += 64 * NPL) v = fmaxf(v, w[j]);
                 key[i] = rq_mono32(v);
             }
             for (int bit = 31; bit >= 12; --bit) {
                 const uint32_t t = prefix | (1u << bit);
                 int c = 0;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) c += __popcll(__ballot(key[i] >= t));
-                if (c >= a.m) prefix = t;
+                for (int i = 0; i < NPL; ++i) c += __popcll(__ballot(key[i] >= t));
+                if (c >= a.m) prefix = t;   // uniform
             }
-        }
+        };
+        if (a.m <= 8) select(RqInt<1>{});
+        else if (a.m <= 64) select(RqInt<4>{});
+        else select(RqInt<8>{});
         // prefix == 0 (fewer than m partitions hold anything): unmono gives NaN -> use -inf = "every bin"
-        if (lane == 0) thr_s = prefix > rq_mono32(NEG_INF) ? rq_unmono32(prefix) : NEG_INF;
+        if (lane == 0) {
+            float T0 = NEG_INF;
+            if (prefix > rq_mono32(NEG_INF)) {
+                const float P = rq_unmono32(prefix);
+                const float e = a.metric == 0 ? a.eps : a.eps * a.max_row_norm;
+                T0 = P - 2.25f * e - 4e-6f * fabsf(P);   // margin: the 1e-6 relative slack of the certificate and fp32 rounding
+            }
+            thr_s = T0;
+        }
     }
     __syncthreads();
     const float T = thr_s;

@@ -127,6 +127,27 @@ def test_certificate_ladder_reaches_exact_scan():
     idx.close()
 
 
+def test_dense_neighbourhoods_certify_without_a_second_pass():
+    """Passages of one document are consecutive rows with nearly equal scores: several rows of one 64-row bin
+    reach the threshold and the scores around the k-th one are denser than the scan's error bound.  The tail's
+    threshold adapts to that (T = P_k - 2 eps): results are exact AND no query needs the widen / exact ladder."""
+    rng = np.random.default_rng(123)
+    n, per_doc = 80_000, 16
+    docs = rng.standard_normal((n // per_doc, 768)).astype(np.float32)
+    x = docs[np.arange(n) // per_doc] + 0.5 * rng.standard_normal((n, 768)).astype(np.float32)
+    x16 = orc.prepare_rows_f32(x, normalize=True)
+    q = docs[rng.integers(0, n // per_doc, size=64)] + 0.3 * rng.standard_normal((64, 768)).astype(np.float32)
+    q[5] = x16[4242].astype(np.float32)                      # an exact copy of a stored row
+    idx = nat.NativeIndex(768, 0)
+    idx.add_f16(x16)
+    for k in (10, 50):
+        idx.reset_timing()
+        _check(idx, x16, q, k)
+        t = idx.timing()
+        assert t["widened"] == 0 and t["exact_scans"] == 0, t
+    idx.close()
+
+
 def test_clustered_near_ties():
     x16 = orc.synthetic_corpus(50_000, 768, seed=8, clustered=True)
     idx = nat.NativeIndex(768, 0)
