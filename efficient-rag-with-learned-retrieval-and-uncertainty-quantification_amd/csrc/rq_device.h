@@ -36,6 +36,7 @@ __host__ __device__ static inline float rq_unmono32(uint32_t k) {
 // key = (mono(score) << 32) | (0xffffffff - index): sorts by score desc, then index asc.
 // key 0 is reserved for "empty".
 __host__ __device__ static inline uint64_t rq_make_key(float score, uint32_t index) {
+    if (score == 0.f) score = 0.f;   // -0.0 (an underflowed negative) ranks with +0.0: equal scores order by row
     return ((uint64_t)rq_mono32(score) << 32) | (uint64_t)(0xffffffffu - index);
 }
 __host__ __device__ static inline float rq_key_score(uint64_t key) { return rq_unmono32((uint32_t)(key >> 32)); }
@@ -44,6 +45,7 @@ __host__ __device__ static inline uint32_t rq_key_index(uint64_t key) { return 0
 // Upper bound of a float in its 16 high bits: positive values round the magnitude up, negative ones truncate
 // (toward zero = up); -inf stays -inf.  The low 16 bits of the result are zero.
 __host__ __device__ static inline uint32_t rq_up16(float f) {
+    if (f == 0.f) f = 0.f;           // -0.0 -> +0.0 so that the codes below stay monotone
     uint32_t u;
     __builtin_memcpy(&u, &f, 4);
     return (u & 0x80000000u) ? (u & 0xffff0000u) : ((u + 0xffffu) & 0xffff0000u);
@@ -55,8 +57,8 @@ __host__ __device__ static inline uint32_t rq_up16(float f) {
 //       [5:0]   row of the second largest
 // Every decoded value is an UPPER bound of the true one, which is all the exactness argument needs.
 #define RQ_BIN_ROWS 64
-#define RQ_STAGE_QUADS 32       // records per query a scan workgroup parks in LDS before it writes them out
 __host__ __device__ static inline uint32_t rq_up26(float f) {
+    if (f == 0.f) f = 0.f;
     uint32_t u;
     __builtin_memcpy(&u, &f, 4);
     return (u & 0x80000000u) ? (u & 0xffffffc0u) : ((u + 63u) & 0xffffffc0u);

@@ -35,6 +35,10 @@ extern __shared__ __attribute__((aligned(16))) char rq_smem[];
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
+// Records per query a scan workgroup parks in LDS: covers a whole range at the usual grid (1M rows: 30.5 quads per
+// workgroup with 64-query workgroups, 61 with the 128-query ones, which run one per CU and have the LDS for it).
+__host__ __device__ static constexpr int rq_stage_quads(int QW) { return QW == 8 ? 64 : 32; }
+
 template <int N>
 __device__ __forceinline__ void rq_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -87,7 +91,8 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
     const int nst = nloc * NSTQ;
     const char* xb = (const char*)a.x;
     char* norm_lds = rq_smem + S * STAGE_BYTES;                 // [2 parities][64 row scales], shared by the waves
-    uint2* const stg = (uint2*)(norm_lds + 512);                // [16 * QW queries][RQ_STAGE_QUADS] finished records
+    constexpr int SQ = rq_stage_quads(QW);                      // records per query parked in LDS before they are written out
+    uint2* const stg = (uint2*)(norm_lds + 512);                // [16 * QW queries][SQ] finished records
 
     auto issue = [&](int st, int slot) {
         const int lq = st / NSTQ, t = (st / KS) & 3, kh = st % KS;
@@ -123,7 +128,7 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
         for (int s = 0; s < 24; ++s) asm volatile("" : "+v"(qf[s]));   // ordinary loads retired before the main loop
     }
 
-    // Finished records wait in LDS and leave in ONE burst per RQ_STAGE_QUADS quads (normally once, at the end of the
+    // Finished records wait in LDS and leave in ONE burst per SQ quads (normally once, at the end of the
     // workgroup's range).  Stores inside the streaming loop are what this kernel is sensitive to: every store
     // instruction that touches 16 different lines holds up the CU's vector-memory address pipe for ~500 cycles
     // (TCP_TCP_TA_ADDR_STALL / _DATA_STALL counters), and the DMA loads queue behind it.  Measured per launch (same
@@ -131,11 +136,12 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
     // 8-byte record per quad stored every 4 quads +32 us (non-temporal / write-through / plain alike, any ring depth,
     // any position inside the stage), every quad +60 us.
     auto flush = [&](int quad0, int count) {
-        // each wave writes the rows of its own 16 queries: 2 queries x 32 records (256-byte runs) per instruction
+        // each wave writes the rows of its own 16 queries: 64 / SQ queries x SQ records (runs of 8 SQ bytes) per instruction
+        constexpr int QPI = 64 / SQ;
 #pragma unroll 1
-        for (int i = 0; i < 8; ++i) {
-            const int ql = 16 * wave + 2 * i + (lane >> 5), j = lane & (RQ_STAGE_QUADS - 1);
-            if (j < count && ql < a.nq_valid) a.bins[(int64_t)ql * a.bins_stride + quad0 + j] = stg[ql * RQ_STAGE_QUADS + j];
+        for (int i = 0; i < 16 / QPI; ++i) {
+            const int ql = 16 * wave + QPI * i + lane / SQ, j = lane & (SQ - 1);
+            if (j < count && ql < a.nq_valid) a.bins[(int64_t)ql * a.bins_stride + quad0 + j] = stg[ql * SQ + j];
         }
     };
     for (int lq = 0; lq < nloc; ++lq) {
@@ -203,11 +209,11 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
         wmax = fmaxf(wmax, m1);
         if (kg == 0) {   // the four lane groups hold the same record
             const uint32_t c2 = rq_code16(m2), c3 = rq_code16(m3), d = c2 - c3;   // c3 <= c2
-            stg[(16 * wave + r16) * RQ_STAGE_QUADS + (lq & (RQ_STAGE_QUADS - 1))] =
+            stg[(16 * wave + r16) * SQ + (lq & (SQ - 1))] =
                 make_uint2(rq_up26(m1) | (ap & 63u), (c2 << 16) | ((d < 1023u ? d : 1023u) << 6) | ((ap >> 8) & 63u));
         }
-        if ((lq & (RQ_STAGE_QUADS - 1)) == RQ_STAGE_QUADS - 1 || lq == nloc - 1)
-            flush(q_lo + (lq & ~(RQ_STAGE_QUADS - 1)), (lq & (RQ_STAGE_QUADS - 1)) + 1);
+        if ((lq & (SQ - 1)) == SQ - 1 || lq == nloc - 1)
+            flush(q_lo + (lq & ~(SQ - 1)), (lq & (SQ - 1)) + 1);
     }
     // per-workgroup maximum of every query: wgmax[query][workgroup]
     wmax = fmaxf(wmax, __shfl_xor(wmax, 16, 64));
@@ -215,9 +221,9 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
     if (kg == 0 && 16 * wave + r16 < a.nq_valid) a.wgmax[(int64_t)(16 * wave + r16) * a.wgmax_stride + b] = wmax;
 }
 
-// ring + [2 parities][64 row scales] + record staging [16 * QW queries][RQ_STAGE_QUADS]
+// ring + [2 parities][64 row scales] + record staging [16 * QW queries][rq_stage_quads(QW)]
 static constexpr size_t rq_scan_lds_bytes(int S, int KS, int QW) {
-    return (size_t)S * (24576 / KS) + 512 + (size_t)16 * QW * RQ_STAGE_QUADS * 8;
+    return (size_t)S * (24576 / KS) + 512 + (size_t)16 * QW * rq_stage_quads(QW) * 8;
 }
 
 template <int S, bool NT, int PF, int OCC, int KS, int QW>
@@ -271,7 +277,7 @@ hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int ks, int qw, bo
     RQ_CASE(4, 4, 2, 2, 4) RQ_CASE(6, 4, 2, 2, 4)
     RQ_CASE(5, 6, 2, 2, 4) RQ_CASE(6, 12, 2, 2, 4)
     RQ_CASE(2, 4, 2, 1, 4) RQ_CASE(3, 4, 2, 1, 4) RQ_CASE(3, 12, 2, 1, 4) RQ_CASE(2, 1, 3, 1, 4) RQ_CASE(4, 4, 2, 1, 4)
-    RQ_CASE(3, 4, 2, 1, 8) RQ_CASE(4, 4, 2, 1, 8) RQ_CASE(2, 4, 2, 1, 8)
+    RQ_CASE(3, 4, 2, 1, 8)
 #undef RQ_CASE
     return hipErrorInvalidValue;
 }

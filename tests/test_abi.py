@@ -10,6 +10,7 @@ import pytest
 from rag_uq_amd import _native
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(os.path.dirname(os.path.abspath(_native.__file__)), "csrc")
 
 
 def _declared_symbols():
@@ -69,3 +70,18 @@ def test_key_packing_roundtrip_matches_device_encoding():
     assert d.pack_keys(np.float32([1.0]), np.int64([-1]))[0] == 0
     ms, mr = d.merge_keys_host(np.array([[k2[0], 0, k2[1]]], dtype=np.uint64), 4)
     assert mr.tolist() == [[3, 7, -1, -1]] and ms[0, :2].tolist() == [0.5, 0.5]
+
+
+def test_record_codec_properties_on_the_host(tmp_path):
+    """csrc/rq_device.h's bit-level helpers (order-preserving keys, rounded-up record fields) compiled for the host with
+    hipcc and checked on a few hundred thousand values: every decoded field is an upper bound, every code is monotone."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(os.path.dirname(__file__), "native", "codec_check.cpp")
+    exe = str(tmp_path / "codec_check")
+    subprocess.run([hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", "-I", CSRC, src, "-o", exe], check=True, timeout=600)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]

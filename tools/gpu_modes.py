@@ -15,7 +15,7 @@ for lo in range(0, N, 125_000):
 qs = [torch.randn((B, 768), device=dev, generator=g) for _ in range(8)]
 streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
 outs = [(torch.empty((B, k), device=dev), torch.empty((B, k), device=dev, dtype=torch.int64), torch.empty((B, k), device=dev, dtype=torch.int64), torch.empty((B,), device=dev, dtype=torch.int32)) for _ in range(3)]
-def run(ns, iters=60):
+def run(ns, iters=int(os.environ.get("RQ_ITERS", 60))):
     def go(i):
         j = i % ns; o = outs[j]
         idx.search_device(qs[i % 8], B, k, 0, o[0], o[1], o[2], o[3], streams[j].cuda_stream)
@@ -33,9 +33,9 @@ def run(ns, iters=60):
 for opts in os.environ.get("RQ_OPTSETS", "ring=4,prefetch=4,wg_per_cu=2").split(";"):
     for o in opts.split(","):
         a, b = o.split("="); idx.set_option(a, float(b))
-    for pipe in (0, 1):
-        for prof in (0, 1):
-            for ns in (1, 2, 3):
+    for pipe in [int(v) for v in os.environ.get("RQ_PIPES", "0,2").split(",")]:
+        for prof in (0,):
+            for ns in [int(v) for v in os.environ.get("RQ_STREAMS", "1,2").split(",")]:
                 idx.set_option("pipeline", pipe); idx.set_option("profile", prof)
                 e2e, host, scan = run(ns)
                 print(f"{opts:32s} pipeline={pipe} profile={prof} streams={ns}: e2e {e2e:7.1f} us/batch  host-enqueue {host:6.1f} us/call  scan(ev) {scan:6.1f} us", flush=True)
