@@ -84,6 +84,9 @@ def main() -> None:
     idx.reserve(max(n_local, 1))
     idx.set_row_offset(row_lo)
     idx.set_option("pipeline", args.pipeline)
+    for opt in filter(None, os.environ.get("RQ_BENCH_OPTS", "").split(",")):      # development: e.g. RQ_BENCH_OPTS=wg_per_cu=3
+        name, val = opt.split("=")
+        idx.set_option(name, float(val))
     # One GPU: one caller stream, so scan launches never overlap each other and the per-launch HIP events (and
     # rocprofv3) read the kernel's own duration; the tail of batch i hides inside the scan launch of batch i+1
     # (pipeline 2).  Several GPUs (125k-row shards, ~35 us steps): two caller streams also hide the query prep
@@ -297,7 +300,15 @@ def main() -> None:
             fn(qh, k)
             tcpu += time.perf_counter() - tb
             nb += 1
+        # the reference's own call pattern: one query per call (streaming_index.py:338-370), a few calls
+        n1, t1 = 0, 0.0
+        while t1 < 2.0 and n1 < 16:
+            tb = time.perf_counter()
+            fn(q_host[n1 % B: n1 % B + 1], k)
+            t1 += time.perf_counter() - tb
+            n1 += 1
         out["cpu_baseline"] = {"value": nb * B / tcpu, "unit": "queries/s", "cores": cores, "kind": "port",
+                               "one_query_per_call": {"value": n1 / t1, "unit": "queries/s", "calls": n1},
                                "sample": f"{nb} batches of {B} queries over the full {n_local}x{DIM} corpus, oracle/dense_oracle.py "
                                          f"Fp32BruteForce variant '{best}' (fp32 OpenBLAS GEMM + argpartition; one-batch trials: "
                                          + ", ".join(f"{n_}: {t_ * 1e3:.0f} ms" for n_, t_ in trial.items()) + ")"}
