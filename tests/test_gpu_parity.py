@@ -225,6 +225,42 @@ def test_deferred_tails_over_many_batches(mode):
     idx.close()
 
 
+def test_two_streams_with_fused_tails_like_the_multi_gpu_bench():
+    """bench.py at N > 1: two caller streams alternate, each with deferred (fused) tails, keys of 16 batches collected
+    in one buffer before they are read.  Every batch must be exact after the flushes."""
+    import torch
+    x16 = orc.synthetic_corpus(50_000, 768, seed=91)
+    idx = nat.NativeIndex(768, 0)
+    idx.add_f16(x16)
+    idx.set_row_offset(1_000_000)
+    idx.set_option("pipeline", 2)
+    dev = torch.device("cuda:0")
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    B, k, nb = 64, 10, 16
+    qs = [orc.synthetic_queries(B, 768, seed=400 + i) for i in range(nb)]
+    dq = [torch.from_numpy(q).to(dev) for q in qs]
+    keys = torch.zeros((nb, B, k), device=dev, dtype=torch.int64)
+    sc = torch.empty((nb, B, k), device=dev); rw = torch.empty((nb, B, k), device=dev, dtype=torch.int64)
+    stt = torch.ones((nb, B), device=dev, dtype=torch.int32)
+    torch.cuda.synchronize()
+    for rep in range(2):                                  # second round reuses every workspace
+        for i in range(nb):
+            idx.search_device(dq[i], B, k, 0, sc[i], rw[i], keys[i], stt[i], streams[i % 2].cuda_stream)
+        for s in streams:
+            idx.search_flush_device(s.cuda_stream)
+        torch.cuda.synchronize()
+        assert int(stt.sum()) == 0
+        from rag_uq_amd import distributed as d
+        for i in range(nb):
+            es, er = orc.dense_topk(qs[i], x16, k, row_offset=1_000_000)
+            assert np.array_equal(rw[i].cpu().numpy(), er)
+            ks, kr = d.unpack_keys(keys[i].cpu().numpy().view(np.uint64))
+            assert np.array_equal(kr, er) and float(np.abs(ks - es).max()) <= SCORE_TOL
+        stt.fill_(1); rw.fill_(-7)
+        torch.cuda.synchronize()
+    idx.close()
+
+
 def test_save_load_roundtrip(tmp_path):
     x16 = orc.synthetic_corpus(3001, 100, seed=2)
     idx = nat.NativeIndex(100, 0)

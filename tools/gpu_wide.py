@@ -17,9 +17,12 @@ for B in (64, 128, 256, 1024):
     for wide in (0, 1):
         idx.set_option("wide_batch", wide)
         for i in range(3): idx.search_device(q, B, k, 0, o[0], o[1], o[2], o[3], 0)
+        idx.set_option("profile", 1); idx.reset_timing()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for i in range(10): idx.search_device(q, B, k, 0, o[0], o[1], o[2], o[3], 0)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+        t = idx.timing(); idx.set_option("profile", 0)
+        scan_us = t["scan_ms"] * 1e3 / max(t["scan_launches"], 1)
         rows = o[1].cpu().numpy().copy()
         if ref is None: ref = rows
-        print(f"B={B:5d} wide_batch={wide}: {dt*1e6:8.1f} us/call  {B/dt:10.0f} q/s  same_rows={bool(np.array_equal(rows, ref))} uncertified={int(o[3].sum())}", flush=True)
+        print(f"B={B:5d} wide_batch={wide}: scan launch {scan_us:6.1f} us x {t['scan_launches'] // 10}  {dt*1e6:8.1f} us/call  {B/dt:10.0f} q/s  same_rows={bool(np.array_equal(rows, ref))} uncertified={int(o[3].sum())}", flush=True)
