@@ -23,7 +23,10 @@ torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 40
 t = idx.timing()
 print("scan %%.1f us  e2e(single stream, profiled) %%.1f us" %% (t["scan_ms"] * 1e3 / t["scan_launches"], dt * 1e6))
 ''' % ROOT
-libs = {"old": os.path.join(ROOT, "_ab", "librq_old.so"), "new": ""}
+import glob
+libs = {"current build": ""}
+for f in sorted(glob.glob(os.path.join(ROOT, "_ab", "librq_*.so"))):      # alternative builds dropped into _ab/
+    libs[os.path.basename(f)[6:-3]] = f
 for rnd in range(3):
     for name, path in libs.items():
         env = dict(os.environ)
