@@ -5,7 +5,7 @@
 //   rownorm64  [cap]      fp64 L2 norm of the stored row               (exact re-score)
 //   inv_norm   [cap]      fp32 1/norm, 0 for zero rows and pad rows     (scan, cosine)
 //   ones       [cap]      fp32 1.0 for rows < n, 0 beyond              (scan, inner product; lazy)
-// plus one workspace per stream (query fragments, pooled bin maxima, bin keys, candidate keys).
+// plus one workspace per stream (query fragments, per-bin scan records, bin keys, candidate keys).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

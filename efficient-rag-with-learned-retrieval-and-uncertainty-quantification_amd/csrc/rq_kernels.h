@@ -12,7 +12,7 @@ struct RqScanArgs {
     int64_t n_rows;           // valid rows of the shard
     int nquads;               // ceil(n_rows / 64)
     int nq_valid;             // queries of this block that are real (<= QB)
-    float* wgmax;             // [QB][wgmax_stride] best pooled value per (query, scan workgroup)
+    float* wgmax;             // [QB][wgmax_stride] largest approximate score per (query, scan workgroup)
     int wgmax_stride;         // >= grid
 };
 #define RQ_WGMAX_STRIDE 1024   // scan grids never exceed this many workgroups

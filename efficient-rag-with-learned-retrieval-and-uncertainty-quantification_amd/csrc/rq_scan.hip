@@ -12,7 +12,7 @@
 //   * Corpus rows reach LDS by LDS-DMA (global_load_lds_dwordx4): every wave-instruction moves
 //     1 KiB contiguous, no VGPRs, and stays in flight across barriers (counted vmcnt, raw s_barrier).
 //     A stage = 16 rows x 384 elements (12 KiB, KS = 2) or 16 whole rows (24 KiB, KS = 1); S stages
-//     form a ring, S-1 are in flight.  Every variant measured lands within 1 % of 6.2 TB/s.
+//     form a ring, S-1 are in flight.  Every variant measured lands within 2 % of the same rate (6.3-6.5 TB/s).
 //   * The stage rows alias in LDS banks, so the 16-byte chunks are XOR-swizzled with the row number on
 //     the DMA *source* address and on the ds_read_b128 address (LDS image stays lane-linear as
 //     LDS-DMA requires).
@@ -115,7 +115,7 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
     }
     int cslot = 0;   // slot of the stage being consumed
     const float NEG_INF = -__builtin_huge_valf();
-    float wmax = NEG_INF;   // best pooled value this lane has produced (feeds the pass-2 threshold)
+    float wmax = NEG_INF;   // largest approximate score this lane has produced (feeds the tail's threshold)
 
     // ---- query fragments: B[k = 8*kg + j][col = r16] of k-step s == qh[16*wave + r16][32*s + 8*kg + j]
     //      (unit-norm fp16 queries written by rq_prep_queries_kernel); loaded while the first stages are in flight

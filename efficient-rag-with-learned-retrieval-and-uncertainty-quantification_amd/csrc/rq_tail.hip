@@ -1,20 +1,20 @@
-// rq_tail.hip -- everything after the corpus scan in ONE launch (the common case: <= 128 bins wanted, k <= 128).
+// rq_tail.hip -- everything after the corpus scan in ONE launch (the common case: k <= 128).
 //
 // grid (chunks of 512*NV bins, B queries), 256 threads.  Each workgroup
-//   A. derives the threshold T = m-th largest partition maximum (partitions = groups of the scan's per-workgroup
-//      maxima; valid because distinct scan workgroups own distinct bins, so at least m bins reach T) with a
-//      20-bit ballot radix select in wave 0,
-//   B. finds the bins of its chunk with pooled >= T and turns them into ROW JOBS: the bin's arg-max row alone when
-//      the bin's second-largest approximate score (aux word, 16-bit upper bound) is below T -- the usual case --
-//      or all 64 rows of the bin otherwise,
+//   A. derives the threshold T = P - 2.25 eps, P = the k-th largest partition maximum (partitions = groups of the
+//      scan's per-workgroup maxima; distinct scan workgroups own distinct bins, so at least k rows reach P and the
+//      k-th exact score is >= P - eps) with a 20-bit ballot radix select in wave 0,
+//   B. finds the bins of its chunk whose largest score reaches T and turns them into ROW JOBS from the bin's 8-byte
+//      scan record (rq_device.h): the arg-max row alone when the bound on the second-largest score is below T -- the
+//      usual case --, the best two rows when only the bound on the third-largest is, all 64 rows of the bin otherwise,
 //   C. re-scores the job rows exactly in fp64 (16 lanes per row, 8 rows of loads in flight per wave) and appends the
 //      (score, row) keys to the query's compact candidate list with 8-byte write-through (sc1) stores,
 //   D. publishes: every wave drains vmcnt, workgroup barrier, ONE lane draws a ticket (agent-scope atomic add).  The
 //      workgroup that draws the last ticket of its query reads the keys with sc1 loads only, ranks them, writes the
 //      exact top-k and the certificate, and resets the counters.  No fences: a release fence per workgroup
 //      serialises on the L2 write-back (measured +60 us per launch).
-// Exactness: a row that is not re-scored has approximate score < T (it is either in a bin with pooled < T, or a
-// non-arg-max row of a bin whose second-largest score is < T), so its exact score is < T + eps; see rq_final_body.h.
+// Exactness: a row that is not re-scored has approximate score < T (its bin's largest, second- or third-largest bound
+// is below T), so its exact score is < T + eps < s_k; see rq_final_body.h and DESIGN.md 4.2.
 // Replaces reference rag_uq/streaming_index.py:355-368 (collection.query + `1 - distance`) after the scan.
 #include "rq_device.h"
 #include "rq_kernels.h"

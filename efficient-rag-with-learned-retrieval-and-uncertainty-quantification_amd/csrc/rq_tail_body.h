@@ -8,7 +8,7 @@
 #define RQ_TAIL_HITCAP 256     // candidate bins one workgroup can hold
 #define RQ_TAIL_JOBCAP 2048    // row jobs one workgroup can hold
 
-// LDS of one tail workgroup (13.7 KB): static in rq_tail_kernel, carved from the scan's ring in the fused kernel.
+// LDS of one tail workgroup (20 KB): static in rq_tail_kernel, carved from the scan's LDS in the fused kernel.
 struct __attribute__((aligned(16))) RqTailLds {
     float qs[RQ_DPAD];            // the raw query, shared by the four waves
     double qpart[4];
