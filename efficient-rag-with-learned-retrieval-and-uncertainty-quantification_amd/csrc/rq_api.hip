@@ -97,6 +97,7 @@ struct rq_index {
     int64_t ones_valid = 0;
     double* d_maxnorm = nullptr;   // device scalar, bits of the running max row norm
     double max_row_norm = 0.0;
+    unsigned long long* dbg_stamps = nullptr;   // development (rq_debug_stamps)
     uint64_t scan_seq = 0;         // scan launches seen while profile = 1 (every profile_stride-th one is timed)
     // options
     int ring = 3, prefetch = 1, kstage = 2, wide_batch = 1, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, profile_stride = 1, scan_nostore = 0, fast_tail = 1, pipeline = 0, tail_stop = 0;
@@ -537,6 +538,11 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             }
             if (fused && cx.fused_pending) {
                 cx.fused_pending = false;
+                if (idx->tail_stop == 9) {   // development: fused kernel without its tail workgroups, tail launched after it
+                    HIPCHK(rq_scan_tail_launch(a, cx.fused_tail, 0, nt, grid, s));
+                    RqTailArgs t9 = cx.fused_tail; t9.stop_after = 0;
+                    HIPCHK(rq_tail_launch(t9, cx.fused_B, s));
+                } else
                 HIPCHK(rq_scan_tail_launch(a, cx.fused_tail, cx.fused_B, nt, grid, s));
             } else if (fused) HIPCHK(rq_scan_launch(a, 3, 1, 2, 4, nt, grid, s));
             else if (qb == 128) HIPCHK(rq_scan_launch(a, 3, 4, 1, 8, nt, grid, s));
@@ -559,6 +565,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             ta.max_row_norm = (float)(idx->max_row_norm * (1.0 + 1e-6)); ta.row_offset = idx->row_offset;
             ta.cand = w.cand; ta.rowcount = w.rowcount; ta.done = w.done; ta.ovf = w.ovf;
             ta.out_scores = d_scores; ta.out_rows = d_rows; ta.out_keys = d_keys; ta.out_status = d_status;
+            ta.dbg = idx->dbg_stamps;
             ta.stop_after = idx->tail_stop;
             if (idx->tail_stop) w.counters_zero = false;   // a truncated tail does not reset its counters
             if (fused) {
@@ -719,6 +726,17 @@ extern "C" int rq_merge_keys_device(const uint64_t* d_keys_in, int n_per_query, 
                                     uint64_t* d_keys_out, void* stream) {
     if (!d_keys_in || !d_scores || !d_rows || B < 1 || k < 1 || k > RQ_MAX_K || n_per_query < 0) return set_err(RQ_EINVAL, "bad merge arguments");
     HIPCHK(rq_merge_keys_launch(d_keys_in, n_per_query, B, k, d_scores, d_rows, d_keys_out, (hipStream_t)stream));
+    return RQ_OK;
+}
+
+// ---- development hook: wall-clock (start, end) stamps of every workgroup of the LAST fused launch ------------
+extern "C" int rq_debug_stamps(rq_index* idx, int enable, unsigned long long* out, int max_wgs) {
+    if (!idx) return set_err(RQ_EINVAL, "null index");
+    if (int r = use_device(idx)) return r;
+    HIPCHK(hipDeviceSynchronize());
+    if (enable && !idx->dbg_stamps) { HIPCHK(hipMalloc((void**)&idx->dbg_stamps, 4 * 8192 * sizeof(unsigned long long))); HIPCHK(hipMemset(idx->dbg_stamps, 0, 4 * 8192 * sizeof(unsigned long long))); }
+    if (out && idx->dbg_stamps) HIPCHK(hipMemcpy(out, idx->dbg_stamps, (size_t)4 * std::min(max_wgs, 8192) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (!enable && idx->dbg_stamps) { (void)hipFree(idx->dbg_stamps); idx->dbg_stamps = nullptr; }
     return RQ_OK;
 }
 

@@ -88,6 +88,7 @@ struct RqTailArgs {
     uint64_t* cand;                                // [B][RQ_CAND_CAP] compact candidate keys
     int* rowcount; int* done; int* ovf;            // [B] each, zero before the launch, reset by the kernel
     float* out_scores; int64_t* out_rows; uint64_t* out_keys; int* out_status;
+    unsigned long long* dbg;                       // development: per-workgroup (start, end) wall-clock stamps of the fused launch, or null
     int stop_after;                                // development: 0 = full kernel, 1..4 = return after phase A..D
 };
 // workgroups [0, scan_grid) run the scan `sa`, the rest the tail `ta` of an EARLIER batch 

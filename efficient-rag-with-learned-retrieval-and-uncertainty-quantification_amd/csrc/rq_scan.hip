@@ -239,11 +239,19 @@ __global__ __launch_bounds__(64 * QW, OCC) void rq_scan_kernel(RqScanArgs a) {
 // tail's 16 KB are carved from the ring).
 template <bool NT, int NV>
 __global__ __launch_bounds__(256, 3) void rq_scan_tail_kernel(RqScanArgs sa, RqTailArgs ta, int scan_grid, int tail_chunks) {
+    unsigned long long t0 = 0;
+    if (ta.dbg) t0 = wall_clock64();
     if ((int)blockIdx.x < scan_grid) {
         rq_scan_body<3, NT, 1, 2, 4>(sa, (int)blockIdx.x, scan_grid);
     } else {
         const int t = (int)blockIdx.x - scan_grid;
         rq_tail_body<NV>(ta, t % tail_chunks, t / tail_chunks, tail_chunks, *reinterpret_cast<RqTailLds*>(rq_smem));
+    }
+    if (ta.dbg && threadIdx.x == 0) {
+        ta.dbg[4 * blockIdx.x] = t0; ta.dbg[4 * blockIdx.x + 1] = wall_clock64();
+        // HW_REG_HW_ID (4): wave/simd/cu/sh/se ids;  HW_REG_XCC_ID (20): the XCD
+        ta.dbg[4 * blockIdx.x + 2] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        ta.dbg[4 * blockIdx.x + 3] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20);
     }
 }
 
@@ -306,7 +314,7 @@ static hipError_t rq_scan_tail_launch_t(const RqScanArgs& sa, const RqTailArgs& 
 }
 
 hipError_t rq_scan_tail_launch(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, bool nt, int scan_grid, hipStream_t stream) {
-    if (scan_grid <= 0 || tail_B < 1) return hipErrorInvalidValue;
+    if (scan_grid <= 0 || tail_B < 0) return hipErrorInvalidValue;   // tail_B = 0: development (the fused kernel without tail workgroups)
     if (ta.m < 1 || ta.m > RQ_FAST_MAX_M || ta.k < 1 || ta.k > RQ_FAST_MAX_K) return hipErrorInvalidValue;
     const bool nv1 = rq_tail_small_chunks(ta.nbins, tail_B);   // same rule as rq_tail_launch
     if (nt) return nv1 ? rq_scan_tail_launch_t<true, 1>(sa, ta, tail_B, scan_grid, stream) : rq_scan_tail_launch_t<true, 4>(sa, ta, tail_B, scan_grid, stream);
