@@ -17,9 +17,14 @@ q = torch.randn((64, 768), device=dev)
 sc = torch.empty((64, 10), device=dev); rw = torch.empty((64, 10), device=dev, dtype=torch.int64); st = torch.empty((64,), device=dev, dtype=torch.int32)
 s = torch.cuda.Stream(device=dev)
 lib.rq_debug_stamps(idx._h, 1, None, 0)
-for _ in range(6):
+for opt in filter(None, os.environ.get("RQ_OPTS", "").split(",")):
+    name, val = opt.split("="); idx.set_option(name, float(val))
+idx.set_option("profile", 1); idx.reset_timing()
+for _ in range(12):
     idx.search_device(q, 64, 10, 0, sc, rw, None, st, s.cuda_stream)
 torch.cuda.synchronize()
+tm = idx.timing()
+print(f"options [{os.environ.get('RQ_OPTS', '')}]: HIP-event duration of the scan launches: {tm['scan_ms'] * 1e3 / tm['scan_launches']:.1f} us (avg of {tm['scan_launches']})")
 out = np.zeros((8192, 4), dtype=np.uint64)
 lib.rq_debug_stamps(idx._h, 1, out.ctypes.data, 8192)
 idx.search_flush_device(s.cuda_stream); torch.cuda.synchronize()
