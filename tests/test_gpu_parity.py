@@ -489,6 +489,75 @@ def test_randomised_shapes_sweep():
         idx.close()
 
 
+@pytest.mark.skipif(not os.environ.get("RQ_LONG_SWEEP"), reason="opt-in stress sweep: RQ_LONG_SWEEP=<cases> (minutes on the GPU box)")
+def test_long_structured_sweep():
+    """Opt-in: mid-size shards (the approximate path, not the tiny-shard exact route) with hostile structure --
+    documents of near-identical consecutive rows, tight clusters, long duplicate runs, rows equal to the query,
+    scores denser than the scan's error bound around the k-th -- through the plain, deferred and fused paths."""
+    import torch
+    ncases = int(os.environ["RQ_LONG_SWEEP"])
+    rng = np.random.default_rng(777)
+    dev = torch.device("cuda:0")
+    for case in range(ncases):
+        n = int(rng.choice([9_000, 20_011, 65_536, 100_003, 180_000]))
+        B = int(rng.choice([1, 7, 64, 64, 100]))
+        k = int(rng.choice([1, 10, 10, 50, 100, 128]))
+        metric = int(rng.integers(0, 2))
+        kind = str(rng.choice(["gauss", "docs", "clusters", "dups"]))
+        base = rng.standard_normal((n, 768)).astype(np.float32)
+        if kind == "docs":
+            per = int(rng.choice([4, 16, 70]))
+            docs = rng.standard_normal((n // per + 1, 768)).astype(np.float32)
+            x = docs[np.arange(n) // per] + float(rng.choice([0.05, 0.5])) * base
+            qsrc = docs
+        elif kind == "clusters":
+            cent = rng.standard_normal((int(rng.choice([8, 64])), 768)).astype(np.float32)
+            x = cent[rng.integers(0, len(cent), size=n)] + float(rng.choice([0.02, 0.3])) * base
+            qsrc = cent
+        else:
+            x = base
+            qsrc = base
+            if kind == "dups":
+                for _ in range(4):
+                    lo = int(rng.integers(0, n - 700)); x[lo:lo + int(rng.integers(2, 600))] = x[lo]
+        del base
+        if metric == 1:
+            x *= rng.uniform(0.2, 3.0, size=(n, 1)).astype(np.float32)
+            x16 = x.astype(np.float16)
+        else:
+            x16 = orc.prepare_rows_f32(x, True)
+        q = qsrc[rng.integers(0, len(qsrc), size=B)] + float(rng.choice([0.0, 0.1, 1.0])) * rng.standard_normal((B, 768)).astype(np.float32)
+        q[0] = x16[int(rng.integers(0, n))].astype(np.float32)
+        if B > 2 and rng.random() < 0.3:
+            q[1] = 0
+        idx = nat.NativeIndex(768, 0)
+        idx.add_f16(x16)
+        mode = int(rng.choice([0, 1, 2]))
+        try:
+            if mode == 0:
+                _check(idx, x16, q, k, metric)
+            else:
+                idx.set_option("pipeline", mode)
+                st_ = torch.cuda.Stream(device=dev)
+                dq = torch.from_numpy(q).to(dev)
+                outs = []
+                for rep in range(3):
+                    sc = torch.empty((B, k), device=dev); rw = torch.empty((B, k), device=dev, dtype=torch.int64); stt = torch.empty((B,), device=dev, dtype=torch.int32)
+                    idx.search_device(dq, B, k, metric, sc, rw, None, stt, st_.cuda_stream)
+                    outs.append((sc, rw, stt))
+                for sc, rw, stt in outs:
+                    idx.search_fixup_device(dq, B, k, metric, sc, rw, None, stt, st_.cuda_stream)
+                st_.synchronize()
+                es, er = orc.dense_topk(q, x16, k, metric=metric)
+                for sc, rw, stt in outs:
+                    assert int(stt.sum()) == 0
+                    assert np.array_equal(rw.cpu().numpy(), er)
+                    assert float(np.abs(sc.cpu().numpy() - es).max()) <= SCORE_TOL * max(1.0, float(np.abs(es).max()))
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: n={n} B={B} k={k} metric={metric} kind={kind} mode={mode}: {e}")
+        idx.close()
+
+
 def test_option_validation_and_status_codes():
     idx = nat.NativeIndex(8, 0)
     for name, bad in [("ring", 9), ("bin_tiles", 4), ("wg_per_cu", 0), ("prefetch", 5), ("kstage", 3), ("nonsense", 1)]:
