@@ -496,7 +496,8 @@ def test_long_structured_sweep():
     scores denser than the scan's error bound around the k-th -- through the plain, deferred and fused paths."""
     import torch
     ncases = int(os.environ["RQ_LONG_SWEEP"])
-    rng = np.random.default_rng(777)
+    rng = np.random.default_rng(int(os.environ.get("RQ_SWEEP_SEED", "777")))
+    progress = os.environ.get("RQ_SWEEP_LOG")            # a file that gets a line every few cases (long runs must show life)
     dev = torch.device("cuda:0")
     for case in range(ncases):
         n = int(rng.choice([9_000, 20_011, 65_536, 100_003, 180_000]))
@@ -556,6 +557,9 @@ def test_long_structured_sweep():
         except AssertionError as e:
             raise AssertionError(f"case {case}: n={n} B={B} k={k} metric={metric} kind={kind} mode={mode}: {e}")
         idx.close()
+        if progress and case % 5 == 4:
+            with open(progress, "a") as f:
+                f.write(f"case {case + 1}/{ncases} ok\n")
 
 
 def test_option_validation_and_status_codes():
