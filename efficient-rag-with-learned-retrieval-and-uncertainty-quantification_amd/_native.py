@@ -63,6 +63,7 @@ _SIGNATURES = {
                                        C.c_void_p]),
     "rq_debug_pooled": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     "rq_debug_read_bandwidth": (C.c_double, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "rq_debug_stamps": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "rq_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
     "rq_get_option": (C.c_double, [C.c_void_p, C.c_char_p]),
     "rq_get_timing": (C.c_int, [C.c_void_p, C.POINTER(rq_timing)]),

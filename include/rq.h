@@ -135,6 +135,11 @@ int64_t rq_debug_pooled(rq_index* idx, void* stream, int query, float* out, int6
  * nt: non-temporal loads 0 / 1 / -1 = the scan's own rule.  Negative on error. */
 double rq_debug_read_bandwidth(rq_index* idx, int iters, int nt, int wg_per_cu);
 
+/* Development hook: enable != 0 makes every workgroup of the fused scan + tail launches (option "pipeline" = 2) record
+ * {start, end} wall-clock ticks (100 MHz), HW_ID and XCC_ID; out (may be NULL) receives [max_wgs][4] words of the last
+ * such launch.  enable == 0 switches it off again.  Used by tools/gpu_stamps.py. */
+int rq_debug_stamps(rq_index* idx, int enable, unsigned long long* out, int max_wgs);
+
 const char* rq_last_error(void);
 const char* rq_version(void);
 

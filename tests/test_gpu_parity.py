@@ -562,6 +562,20 @@ def test_long_structured_sweep():
                 f.write(f"case {case + 1}/{ncases} ok\n")
 
 
+def test_measurement_hooks():
+    """rq_debug_read_bandwidth (the box's plain streaming-read rate, bench.py's yardstick) and rq_debug_stamps"""
+    x16 = orc.synthetic_corpus(200_000, 768, seed=5)
+    idx = nat.NativeIndex(768, 0)
+    idx.add_f16(x16)
+    gbs = idx.read_bandwidth(iters=5)
+    assert 500.0 < gbs < 20_000.0, gbs           # 300 MB shard: anything between a slow HBM and the Infinity Cache
+    idx.close()
+    empty = nat.NativeIndex(768, 0)
+    with pytest.raises(nat.RqError):
+        empty.read_bandwidth()
+    empty.close()
+
+
 def test_option_validation_and_status_codes():
     idx = nat.NativeIndex(8, 0)
     for name, bad in [("ring", 9), ("bin_tiles", 4), ("wg_per_cu", 0), ("prefetch", 5), ("kstage", 3), ("nonsense", 1)]:

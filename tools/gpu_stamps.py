@@ -10,8 +10,6 @@ for c in range(0, N, 125_000):
     n = min(125_000, N - c)
     idx.add_f16_device(torch.nn.functional.normalize(torch.randn((n, 768), device=dev), dim=1).half().contiguous(), n)
 lib = nat.load_library()
-lib.rq_debug_stamps.restype = C.c_int
-lib.rq_debug_stamps.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
 idx.set_option("pipeline", 2)
 q = torch.randn((64, 768), device=dev)
 sc = torch.empty((64, 10), device=dev); rw = torch.empty((64, 10), device=dev, dtype=torch.int64); st = torch.empty((64,), device=dev, dtype=torch.int32)
