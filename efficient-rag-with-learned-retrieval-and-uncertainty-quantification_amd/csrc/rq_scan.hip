@@ -237,11 +237,6 @@ __global__ __launch_bounds__(64 * QW, OCC) void rq_scan_kernel(RqScanArgs a) {
 // overlap each other.  Scan variant: ring of 3 half-row stages, prefetch 1 (36 KB ring + 16.5 KB of record staging =
 // 53 760 B of LDS, <= 168 VGPRs), so a CU holds 2 scan workgroups + 1 tail workgroup (3 x 53 760 B <= 160 KB; the
 // tail's 16 KB are carved from the ring).
-template <int NV>
-__device__ __noinline__ void rq_tail_call(const RqTailArgs& ta, int t, int tail_chunks, char* smem) {
-    rq_tail_body<NV>(ta, t % tail_chunks, t / tail_chunks, tail_chunks, *reinterpret_cast<RqTailLds*>(smem));
-}
-
 template <bool NT, int NV>
 __global__ __launch_bounds__(256, 3) void rq_scan_tail_kernel(RqScanArgs sa, RqTailArgs ta, int scan_grid, int tail_chunks) {
     unsigned long long t0 = 0;
@@ -250,7 +245,7 @@ __global__ __launch_bounds__(256, 3) void rq_scan_tail_kernel(RqScanArgs sa, RqT
         rq_scan_body<3, NT, 1, 2, 4>(sa, (int)blockIdx.x, scan_grid);
     } else {
         const int t = (int)blockIdx.x - scan_grid;
-        rq_tail_call<NV>(ta, t, tail_chunks, rq_smem);
+        rq_tail_body<NV>(ta, t % tail_chunks, t / tail_chunks, tail_chunks, *reinterpret_cast<RqTailLds*>(rq_smem));
     }
     if (ta.dbg && threadIdx.x == 0) {
         ta.dbg[4 * blockIdx.x] = t0; ta.dbg[4 * blockIdx.x + 1] = wall_clock64();
