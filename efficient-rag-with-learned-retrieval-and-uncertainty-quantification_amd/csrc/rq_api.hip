@@ -107,6 +107,8 @@ struct rq_index {
     // host-call staging
     float* h_dq = nullptr; float* h_dscores = nullptr; int64_t* h_drows = nullptr; int* h_dstatus = nullptr;
     int h_bcap = 0, h_kcap = 0;
+    // small blocking searches (the reference's one-query-per-call pattern): results leave in ONE copy into pinned memory
+    char* hs_dev = nullptr; char* hs_pin = nullptr; float* hs_pin_q = nullptr; size_t hs_bytes = 0, hs_qfloats = 0;
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t ev_used = 0;
@@ -225,7 +227,9 @@ extern "C" void rq_index_destroy(rq_index* idx) {
         }
     }
     for (auto& ev : idx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-    void* p[] = {idx->x, idx->rownorm64, idx->inv_norm, idx->ones, idx->d_maxnorm, idx->h_dq, idx->h_dscores, idx->h_drows, idx->h_dstatus};
+    if (idx->hs_pin) (void)hipHostFree(idx->hs_pin);
+    if (idx->hs_pin_q) (void)hipHostFree(idx->hs_pin_q);
+    void* p[] = {idx->x, idx->rownorm64, idx->inv_norm, idx->ones, idx->d_maxnorm, idx->h_dq, idx->h_dscores, idx->h_drows, idx->h_dstatus, idx->hs_dev};
     for (void* q : p) if (q) (void)hipFree(q);
     if (idx->own_stream) (void)hipStreamDestroy(idx->own_stream);
     delete idx;
@@ -712,6 +716,46 @@ extern "C" int rq_search(rq_index* idx, const float* queries, int B, int k, int 
         idx->h_bcap = nb; idx->h_kcap = nk;
     }
     hipStream_t s = idx->own_stream;
+    if ((size_t)B * k <= 65536) {
+        // one device block [rows int64 | scores fp32 | status int32] -> one copy into pinned memory -> one synchronisation
+        const size_t off_s = (size_t)B * k * sizeof(int64_t), off_t = off_s + (size_t)B * k * sizeof(float);
+        const size_t bytes = off_t + (size_t)B * sizeof(int), qfloats = (size_t)B * idx->dim;
+        if (bytes > idx->hs_bytes) {
+            if (idx->hs_dev) (void)hipFree(idx->hs_dev);
+            if (idx->hs_pin) (void)hipHostFree(idx->hs_pin);
+            idx->hs_dev = nullptr; idx->hs_pin = nullptr; idx->hs_bytes = 0;
+            HIPCHK(hipMalloc((void**)&idx->hs_dev, bytes));
+            HIPCHK(hipHostMalloc((void**)&idx->hs_pin, bytes, hipHostMallocDefault));
+            idx->hs_bytes = bytes;
+        }
+        if (qfloats > idx->hs_qfloats) {
+            if (idx->hs_pin_q) (void)hipHostFree(idx->hs_pin_q);
+            idx->hs_pin_q = nullptr; idx->hs_qfloats = 0;
+            HIPCHK(hipHostMalloc((void**)&idx->hs_pin_q, qfloats * sizeof(float), hipHostMallocDefault));
+            idx->hs_qfloats = qfloats;
+        }
+        int64_t* d_rows = (int64_t*)idx->hs_dev;
+        float* d_scores = (float*)(idx->hs_dev + off_s);
+        int* d_status = (int*)(idx->hs_dev + off_t);
+        std::memcpy(idx->hs_pin_q, queries, qfloats * sizeof(float));
+        HIPCHK(hipMemcpyAsync(idx->h_dq, idx->hs_pin_q, qfloats * sizeof(float), hipMemcpyHostToDevice, s));
+        if (int r = rq_search_device(idx, idx->h_dq, B, k, metric, d_scores, d_rows, nullptr, d_status, s)) return r;
+        if (int r = flush_tails(idx, s)) return r;   // (option "pipeline": the tail must have run before the copy)
+        HIPCHK(hipMemcpyAsync(idx->hs_pin, idx->hs_dev, bytes, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        const int* st = (const int*)(idx->hs_pin + off_t);
+        bool clean = true;
+        for (int q = 0; q < B; ++q) clean = clean && st[q] == 0;
+        if (!clean) {   // rare: repair on the device, fetch again
+            const int fr = rq_search_fixup_device(idx, idx->h_dq, B, k, metric, d_scores, d_rows, nullptr, d_status, s);
+            if (fr < 0) return fr;
+            HIPCHK(hipMemcpyAsync(idx->hs_pin, idx->hs_dev, off_t, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+        }
+        std::memcpy(out_rows, idx->hs_pin, off_s);
+        std::memcpy(out_scores, idx->hs_pin + off_s, off_t - off_s);
+        return RQ_OK;
+    }
     HIPCHK(hipMemcpyAsync(idx->h_dq, queries, (size_t)B * idx->dim * sizeof(float), hipMemcpyHostToDevice, s));
     if (int r = rq_search_device(idx, idx->h_dq, B, k, metric, idx->h_dscores, idx->h_drows, nullptr, idx->h_dstatus, s)) return r;
     const int fr = rq_search_fixup_device(idx, idx->h_dq, B, k, metric, idx->h_dscores, idx->h_drows, nullptr, idx->h_dstatus, s);
