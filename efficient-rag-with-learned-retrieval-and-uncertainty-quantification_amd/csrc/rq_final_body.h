@@ -2,14 +2,14 @@
 // Run by all 256 threads of the workgroup that drew the last ticket of its query in rq_tail_kernel (rq_tail.hip).
 //
 // The candidates are a compact list of n keys (typically k..3k: one exact re-scored row per candidate bin).
-//   n <= 1024: every key is ranked against all others through LDS (keys are unique) and written by rank;
+//   n <= 2048: every key is ranked against all others through LDS (keys are unique) and written by rank;
 //   n <= 4096: keys stay in registers, k rounds of "extract the maximum" (massive exact ties only).
 #pragma once
 #include "rq_device.h"
 #include "rq_kernels.h"   // RQ_CAND_CAP
 
 struct RqFinalLds {
-    uint64_t skeys[1024];
+    uint64_t skeys[2048];
     uint64_t wbest[2][4];
     uint64_t skth;
     int snz;
@@ -55,7 +55,7 @@ __device__ __forceinline__ void rq_final_body(const RqFinalCore& a, int total, i
     int have = 0;
     uint64_t kth = 0;
     if (tid == 0) { L.skth = 0; L.snz = 0; }
-    if (n <= 1024) {
+    if (n <= 2048) {
         int nz = 0;
         for (int j = tid; j < n; j += 256) L.skeys[j] = __hip_atomic_load(a.cand + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();

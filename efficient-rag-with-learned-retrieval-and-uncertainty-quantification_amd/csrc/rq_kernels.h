@@ -72,8 +72,8 @@ struct RqFinalArgs {
 hipError_t rq_final_launch(const RqFinalArgs& a, int B, hipStream_t stream);
 
 // ---- fast tail (the common case: m <= 128 bins wanted, k <= 128) ----
-#define RQ_FAST_MAX_M 128
-#define RQ_FAST_MAX_K 128
+#define RQ_FAST_MAX_M 320
+#define RQ_FAST_MAX_K 320       // beyond that the 512 partition maxima give too loose a threshold (k = 512: every query overflows)
 #define RQ_CAND_CAP 4096       // candidate keys per query (compact list written by the tail kernel)
 
 // Fused tail: threshold + bin collection + exact re-score + final top-k + certificate in one launch.

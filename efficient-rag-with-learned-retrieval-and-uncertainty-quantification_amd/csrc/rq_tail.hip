@@ -1,4 +1,4 @@
-// rq_tail.hip -- everything after the corpus scan in ONE launch (the common case: k <= 128).
+// rq_tail.hip -- everything after the corpus scan in ONE launch (k <= 320).
 //
 // grid (chunks of 512*NV bins, B queries), 256 threads.  Each workgroup
 //   A. derives the threshold T = P - 2.25 eps, P = the k-th largest partition maximum (partitions = groups of the
