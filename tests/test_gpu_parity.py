@@ -500,7 +500,8 @@ def test_long_structured_sweep():
     progress = os.environ.get("RQ_SWEEP_LOG")            # a file that gets a line every few cases (long runs must show life)
     dev = torch.device("cuda:0")
     for case in range(ncases):
-        n = int(rng.choice([9_000, 20_011, 65_536, 100_003, 180_000]))
+        big = case < int(os.environ.get("RQ_LONG_SWEEP_BIG", "0"))       # the first few cases at the headline size
+        n = 1_000_000 if big else int(rng.choice([9_000, 20_011, 65_536, 100_003, 180_000]))
         B = int(rng.choice([1, 7, 64, 64, 100]))
         k = int(rng.choice([1, 10, 10, 50, 100, 128]))
         metric = int(rng.integers(0, 2))
