@@ -85,3 +85,35 @@ def test_record_codec_properties_on_the_host(tmp_path):
     subprocess.run([hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", "-I", CSRC, src, "-o", exe], check=True, timeout=600)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def _build_c_client(tmp_path):
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    pkg = os.path.dirname(os.path.abspath(_native.__file__))
+    exe = str(tmp_path / "abi_check")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(os.path.dirname(__file__), "native", "abi_check.c"), "-o", exe,
+                    "-L", pkg, "-lrq_hip", "-lm", f"-Wl,-rpath,{pkg}", "-Wl,-rpath,/opt/rocm/lib"], check=True, timeout=300)
+    return exe
+
+
+def test_header_is_plain_c_and_a_c_client_fails_loudly_without_a_gpu(tmp_path):
+    """include/rq.h compiles as C99 with gcc (no HIP, no C++), links against librq_hip.so, and on a box without a GPU
+    the client gets NULL + a message instead of a silent fallback."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("covered by the gpu-marked twin")
+    out = subprocess.run([_build_c_client(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "OK (no device)" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_c_client_searches_on_the_gpu(tmp_path):
+    import subprocess
+    out = subprocess.run([_build_c_client(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "OK (device search)" in out.stdout, out.stdout + out.stderr
