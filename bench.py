@@ -313,9 +313,10 @@ def main() -> None:
                                          f"Fp32BruteForce variant '{best}' (fp32 OpenBLAS GEMM + argpartition; one-batch trials: "
                                          + ", ".join(f"{n_}: {t_ * 1e3:.0f} ms" for n_, t_ in trial.items()) + ")"}
     if use_comm:
-        # N > 1 correctness evidence (outside the timed region): GPU path = per-shard search -> RCCL all-gather ->
-        # device merge; checker = every rank's ORACLE top-k of its own shard -> all-gather -> host merge.
-        from oracle import dense_oracle as orc
+        # N > 1 correctness evidence (outside the timed region): the benchmarked path = approximate scan + certified
+        # re-score per shard -> RCCL all-gather of keys -> device merge, against the library's own EXACT path (every row
+        # of the shard re-scored in fp64, no approximation, no certificate: option slack_bins >= number of bins) ->
+        # all-gather -> host merge.  (The oracle-based version of this check runs in tests/ and, at N = 1, above.)
         from rag_uq_amd import distributed as rqd
         nchk = 4
         o = slots[0]
@@ -327,17 +328,18 @@ def main() -> None:
         g_rows = torch.empty((B, k), device=dev, dtype=torch.int64)
         nat.merge_keys_device(allk.permute(1, 0, 2).contiguous(), world * k, B, k, g_scores, g_rows, None, 0)
         torch.cuda.synchronize()
-        q_host = queries[0][:nchk].cpu().numpy()
-        ls, lr = orc.dense_topk(q_host, idx.get_rows_f16(0, n_local), k, row_offset=row_lo) if n_local else (
-            np.zeros((nchk, k), np.float32), np.full((nchk, k), -1, np.int64))
-        okeys = torch.from_numpy(rqd.pack_keys(ls, lr).view(np.int64).copy()).to(dev)
+        idx.set_option("slack_bins", max(n_local, 64))          # -> the exact fp64 scan of the whole shard
+        e_sc = torch.empty((nchk, k), device=dev); e_rw = torch.empty((nchk, k), device=dev, dtype=torch.int64)
+        e_ky = torch.zeros((nchk, k), device=dev, dtype=torch.int64); e_st = torch.empty((nchk,), device=dev, dtype=torch.int32)
+        if n_local:
+            idx.search_device(queries[0][:nchk].contiguous(), nchk, k, nat.METRIC_COSINE, e_sc, e_rw, e_ky, e_st, 0)
         oall = torch.zeros((world, nchk, k), device=dev, dtype=torch.int64)
-        dist.all_gather_into_tensor(oall, okeys)
+        dist.all_gather_into_tensor(oall, e_ky)
         ms, mr = rqd.merge_keys_host(oall.permute(1, 0, 2).reshape(nchk, world * k).cpu().numpy().view(np.uint64), k)
         got_r = g_rows[:nchk].cpu().numpy()
-        out["recall_at_10"] = orc.recall_at_k(got_r, mr)
-        out["ids_exact"] = bool((got_r == mr).all())
-        out["max_abs_score_err"] = float(np.abs(g_scores[:nchk].cpu().numpy() - ms).max())
+        out["ids_match_exact_fp64_scan"] = bool((got_r == mr).all())
+        out["recall_at_10_vs_exact_fp64_scan"] = float(np.mean([len(set(a.tolist()) & set(b.tolist())) / max(len(b), 1) for a, b in zip(got_r, mr)]))
+        out["max_abs_score_diff_vs_exact_fp64_scan"] = float(np.abs(g_scores[:nchk].cpu().numpy() - ms).max())
     if rank == 0:
         print(json.dumps(out), flush=True)
     idx.close()
