@@ -316,7 +316,15 @@ static hipError_t rq_scan_tail_launch_t(const RqScanArgs& sa, const RqTailArgs& 
 hipError_t rq_scan_tail_launch(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, bool nt, int scan_grid, hipStream_t stream) {
     if (scan_grid <= 0 || tail_B < 0) return hipErrorInvalidValue;   // tail_B = 0: development (the fused kernel without tail workgroups)
     if (ta.m < 1 || ta.m > RQ_FAST_MAX_M || ta.k < 1 || ta.k > RQ_FAST_MAX_K) return hipErrorInvalidValue;
-    const bool nv1 = rq_tail_small_chunks(ta.nbins, tail_B);   // same rule as rq_tail_launch
-    if (nt) return nv1 ? rq_scan_tail_launch_t<true, 1>(sa, ta, tail_B, scan_grid, stream) : rq_scan_tail_launch_t<true, 4>(sa, ta, tail_B, scan_grid, stream);
-    return nv1 ? rq_scan_tail_launch_t<false, 1>(sa, ta, tail_B, scan_grid, stream) : rq_scan_tail_launch_t<false, 4>(sa, ta, tail_B, scan_grid, stream);
+    // Riding tails: as few workgroups as keep every CU's third slot busy once (~256): each tail workgroup costs the
+    // scan a little while it is resident (measured at 1M rows: 256 workgroups of 4096 bins 248.7 us per launch, 512 of
+    // 2048 bins 252.4 us).  The stand-alone launch (rq_tail_launch) prefers more, smaller ones: lower latency.
+    const auto wgs = [&](int nv) { return ((ta.nbins + 512 * nv - 1) / (512 * nv)) * tail_B; };
+    const int nv = wgs(1) <= 384 ? 1 : (wgs(4) <= 384 ? 4 : 8);
+    if (nt) return nv == 1 ? rq_scan_tail_launch_t<true, 1>(sa, ta, tail_B, scan_grid, stream)
+                 : nv == 4 ? rq_scan_tail_launch_t<true, 4>(sa, ta, tail_B, scan_grid, stream)
+                           : rq_scan_tail_launch_t<true, 8>(sa, ta, tail_B, scan_grid, stream);
+    return nv == 1 ? rq_scan_tail_launch_t<false, 1>(sa, ta, tail_B, scan_grid, stream)
+         : nv == 4 ? rq_scan_tail_launch_t<false, 4>(sa, ta, tail_B, scan_grid, stream)
+                   : rq_scan_tail_launch_t<false, 8>(sa, ta, tail_B, scan_grid, stream);
 }
