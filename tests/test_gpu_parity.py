@@ -577,6 +577,40 @@ def test_measurement_hooks():
     empty.close()
 
 
+def test_no_device_memory_leak_over_index_lifetimes():
+    """create -> add -> searches on two streams (plain, deferred, fused, host API) -> destroy, 30 times: the device's
+    free memory must come back (workspaces, pinned staging, debug buffers are all owned by the index)."""
+    import torch
+    dev = torch.device("cuda:0")
+    x16 = orc.synthetic_corpus(30_000, 768, seed=12)
+    q = orc.synthetic_queries(64, 768, seed=13)
+    dq = torch.from_numpy(q).to(dev)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    sc = torch.empty((64, 10), device=dev); rw = torch.empty((64, 10), device=dev, dtype=torch.int64); st = torch.empty((64,), device=dev, dtype=torch.int32)
+
+    def cycle(mode):
+        idx = nat.NativeIndex(768, 0)
+        idx.add_f16(x16)
+        idx.set_option("pipeline", mode)
+        for i in range(4):
+            idx.search_device(dq, 64, 10, 0, sc, rw, None, st, streams[i % 2].cuda_stream)
+        for s_ in streams:
+            idx.search_flush_device(s_.cuda_stream)
+        idx.search(q[:3], 7)
+        torch.cuda.synchronize()
+        idx.close()
+
+    for mode in (0, 1, 2):
+        cycle(mode)                                            # first use of every code path (module load, caches)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(dev)
+    for it in range(30):
+        cycle(it % 3)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(dev)
+    assert free0 - free1 < 64 << 20, f"{(free0 - free1) >> 20} MiB of device memory did not come back"
+
+
 def test_option_validation_and_status_codes():
     idx = nat.NativeIndex(8, 0)
     for name, bad in [("ring", 9), ("bin_tiles", 4), ("wg_per_cu", 0), ("prefetch", 5), ("kstage", 3), ("nonsense", 1)]:
