@@ -229,7 +229,7 @@ extern "C" void rq_index_destroy(rq_index* idx) {
     for (auto& ev : idx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (idx->hs_pin) (void)hipHostFree(idx->hs_pin);
     if (idx->hs_pin_q) (void)hipHostFree(idx->hs_pin_q);
-    void* p[] = {idx->x, idx->rownorm64, idx->inv_norm, idx->ones, idx->d_maxnorm, idx->h_dq, idx->h_dscores, idx->h_drows, idx->h_dstatus, idx->hs_dev};
+    void* p[] = {idx->x, idx->rownorm64, idx->inv_norm, idx->ones, idx->d_maxnorm, idx->h_dq, idx->h_dscores, idx->h_drows, idx->h_dstatus, idx->hs_dev, idx->dbg_stamps};
     for (void* q : p) if (q) (void)hipFree(q);
     if (idx->own_stream) (void)hipStreamDestroy(idx->own_stream);
     delete idx;
