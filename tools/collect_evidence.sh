@@ -8,4 +8,5 @@ timeout -k 10 600 python tools/gpu_clustered.py 2>&1 | grep -v amdgpu.ids > $E/c
 timeout -k 10 400 python tools/gpu_tail.py 2>&1 | grep -v amdgpu.ids > $E/tail_phases.txt
 timeout -k 10 300 python tools/gpu_wide.py 2>&1 | grep -v amdgpu.ids > $E/wide_batches.txt
 timeout -k 10 300 python tools/gpu_readbw.py 2>&1 | grep -v amdgpu.ids > $E/read_probe.txt
+timeout -k 10 300 python tools/gpu_latency.py 2>&1 | grep -v amdgpu.ids > $E/host_api_latency.txt
 ls -la $E
