@@ -190,10 +190,13 @@ def main() -> None:
     # vs 263 k).  RQ_BENCH_PREHEAT_MS=0 switches it off.
     preheat_ms = float(os.environ.get("RQ_BENCH_PREHEAT_MS", "100"))
     t_pre = time.perf_counter()
-    while (time.perf_counter() - t_pre) * 1e3 < preheat_ms:
+    while (time.perf_counter() - t_pre) * 1e3 < preheat_ms:     # rank-local: no collective in here (the ranks' clocks differ)
         for i in range(16):
-            step(i)
-        flush()
+            o = slots[i % N_QUERY_BATCHES]
+            idx.search_device(queries[i % N_QUERY_BATCHES], B, k, nat.METRIC_COSINE, o["scores"], o["rows"], o["keys"], o["status"],
+                              streams[i % len(streams)].cuda_stream)
+        for s in streams:
+            idx.search_flush_device(s.cuda_stream)
         torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
