@@ -9,4 +9,5 @@ timeout -k 10 400 python tools/gpu_tail.py 2>&1 | grep -v amdgpu.ids > $E/tail_p
 timeout -k 10 300 python tools/gpu_wide.py 2>&1 | grep -v amdgpu.ids > $E/wide_batches.txt
 timeout -k 10 300 python tools/gpu_readbw.py 2>&1 | grep -v amdgpu.ids > $E/read_probe.txt
 timeout -k 10 300 python tools/gpu_latency.py 2>&1 | grep -v amdgpu.ids > $E/host_api_latency.txt
+timeout -k 10 120 python tools/gpu_sustained.py 2>&1 | grep -v amdgpu.ids > $E/sustained.txt
 ls -la $E
