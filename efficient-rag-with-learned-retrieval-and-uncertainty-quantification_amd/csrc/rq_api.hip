@@ -100,7 +100,7 @@ struct rq_index {
     unsigned long long* dbg_stamps = nullptr;   // development (rq_debug_stamps)
     uint64_t scan_seq = 0;         // scan launches seen while profile = 1 (every profile_stride-th one is timed)
     // options
-    int ring = 3, prefetch = 1, kstage = 2, wide_batch = 1, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, profile_stride = 1, scan_nostore = 0, fast_tail = 1, pipeline = 0, tail_stop = 0;
+    int ring = 3, prefetch = 1, kstage = 2, wide_batch = 1, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, profile_stride = 1, scan_nostore = 0, fast_tail = 1, pipeline = 0, tail_stop = 0, poison_cand = 0;
     double eps = -1.0;
     std::map<hipStream_t, StreamCtx> ctx;
     hipStream_t own_stream = nullptr;
@@ -344,6 +344,7 @@ extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     else if (s == "fast_tail") idx->fast_tail = (int)v;
     else if (s == "pipeline") { if (v != 0 && v != 1 && v != 2) return set_err(RQ_EINVAL, "pipeline must be 0, 1 or 2"); if (int r = flush_all(idx)) return r; idx->pipeline = (int)v; }
     else if (s == "tail_stop") idx->tail_stop = (int)v;
+    else if (s == "poison_cand") idx->poison_cand = (int)v;   // test hook: candidate lists are filled with 0xff..ff keys before every tail
     else return set_err(RQ_EINVAL, "unknown option '%s'", name);
     return RQ_OK;
 }
@@ -429,6 +430,15 @@ static int fill_empty(int B, int k, float* d_scores, int64_t* d_rows, uint64_t* 
     return RQ_OK;
 }
 
+// Test hook ("poison_cand"): before a tail runs, its queries' candidate lists are overwritten with the largest
+// possible key.  A consumer that reads a candidate slot it was not handed (a stale line) then returns row 0 with a NaN
+// score at rank 1, which no oracle comparison can miss -- instead of a plausible key of an earlier batch.
+static int poison_cand(const rq_index* idx, const RqTailArgs& t, int B, hipStream_t s) {
+    if (!idx->poison_cand || !t.cand || B <= 0) return RQ_OK;
+    HIPCHK(hipMemsetAsync(t.cand, 0xff, (size_t)B * RQ_CAND_CAP * sizeof(uint64_t), s));
+    return RQ_OK;
+}
+
 // Make `s` wait for every tail still running on the internal tail stream of `s` (pipeline = 1) and launch the
 // tail that was waiting for the next scan (pipeline = 2).
 static int flush_tails(rq_index* idx, hipStream_t s) {
@@ -437,6 +447,7 @@ static int flush_tails(rq_index* idx, hipStream_t s) {
     StreamCtx& c = it->second;
     if (c.fused_pending) {
         c.fused_pending = false;
+        if (int r = poison_cand(idx, c.fused_tail, c.fused_B, s)) return r;
         HIPCHK(rq_tail_launch(c.fused_tail, c.fused_B, s));
     }
     for (int p = 0; p < 2; ++p)
@@ -542,6 +553,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             }
             if (fused && cx.fused_pending) {
                 cx.fused_pending = false;
+                if (int r = poison_cand(idx, cx.fused_tail, cx.fused_B, s)) return r;
                 if (idx->tail_stop == 9) {   // development: fused kernel without its tail workgroups, tail launched after it
                     HIPCHK(rq_scan_tail_launch(a, cx.fused_tail, 0, nt, grid, s));
                     RqTailArgs t9 = cx.fused_tail; t9.stop_after = 0;
@@ -589,6 +601,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
                 }
                 HIPCHK(hipEventRecord(idx->events[idx->ev_used].first, ts));
             }
+            if (int r = poison_cand(idx, ta, B, ts)) return r;
             HIPCHK(rq_tail_launch(ta, B, ts));
             if (tprof) { HIPCHK(hipEventRecord(idx->events[idx->ev_used].second, ts)); idx->ev_used++; }
             if (piped) { HIPCHK(hipEventRecord(cx.ev_tail[par], cx.tail)); cx.tail_pending[par] = true; }

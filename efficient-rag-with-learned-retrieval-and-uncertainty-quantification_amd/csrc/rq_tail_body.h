@@ -204,12 +204,21 @@ __device__ __forceinline__ void rq_tail_body(const RqTailArgs& a, const int chun
     }
     if (a.stop_after == 3) return;
 
-    // ---- D. publish (MI355X_MICROARCH.md "Valid forms", first table row)
+    // ---- D. publish.  Producer side (every workgroup): all candidate keys were stored write-through (sc1), every
+    //      storing wave drains vmcnt(0), workgroup barrier, ONE lane draws the ticket (agent-scope atomic add).
+    //      Consumer side (the workgroup whose ticket is the query's last): ONE agent-scope acquire by the lane that drew
+    //      the ticket, s_waitcnt vmcnt(0) so that the barrier below is held until the L1 invalidate has completed, workgroup
+    //      barrier, then the loads (which stay sc1 as well).  This is MI355X_MICROARCH.md "Valid forms", Consumer bullet,
+    //      in its unconditional form: several tail workgroups share a CU here (and, fused, sit beside two scan workgroups),
+    //      which is outside the "one per CU" cell the sc1-loads-only form was measured for.  Cost: one buffer_inv per QUERY
+    //      (64 per launch, in parallel), not per workgroup.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
         const int ticket = __hip_atomic_fetch_add(&a.done[q], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (ticket == nchunks - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             total_s = __hip_atomic_load(&a.rowcount[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ovf_s = __hip_atomic_load(&a.ovf[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // counters back to zero for the next launch on this workspace

@@ -404,6 +404,73 @@ def test_full_size_properties(n):
     idx.close()
 
 
+def _device_corpus(idx, n, seed0, chunk=125_000):
+    """Gaussian unit rows generated in HBM chunk by chunk (chunk c seeded seed0 + c), as bench.py does."""
+    import torch
+    dev = torch.device("cuda:0")
+    idx.reserve(n)
+    for c in range((n + chunk - 1) // chunk):
+        m = min(chunk, n - c * chunk)
+        g = torch.Generator(device=dev); g.manual_seed(seed0 + c)
+        x = torch.nn.functional.normalize(torch.randn((m, 768), device=dev, generator=g), dim=1).half().contiguous()
+        idx.add_f16_device(x, m)
+        del x
+
+
+@pytest.mark.parametrize("n,expect_nv", [(1_000_000, 8), (300_000, 4)])
+def test_fused_headline_instantiation_matches_oracle(n, expect_nv):
+    """The kernel bench.py times: rq_scan_tail_kernel<NT = true, NV> (option pipeline = 2: the tail of batch i rides in
+    the scan launch of batch i + 1), one stream, consecutive 64-query batches -- at the headline size (1M rows: non-temporal
+    loads, 4096-bin tail chunks, NV = 8) and at 300k rows (NT, NV = 4).  ALL 64 queries of every batch are compared with
+    the oracle: rows identical, |score difference| <= 1e-6, certificate status 0.  The candidate lists are poisoned with
+    0xff..ff keys before every tail (option poison_cand): a consumer workgroup that read a candidate slot it was not handed
+    would return row 0 / NaN at rank 1 (the cross-workgroup hand-off of rq_tail_body.h under uneven load: the tail
+    workgroups share their CUs with two streaming scan workgroups)."""
+    import torch
+    dev = torch.device("cuda:0")
+    idx = nat.NativeIndex(768, 0)
+    _device_corpus(idx, n, 1235)
+    assert len(idx) == n
+    nbins = (n + 63) // 64
+    wgs = lambda nv: ((nbins + 512 * nv - 1) // (512 * nv)) * 64          # rq_scan_tail_launch's rule (csrc/rq_scan.hip)
+    assert (1 if wgs(1) <= 384 else 4 if wgs(4) <= 384 else 8) == expect_nv
+    assert n * 1536 > (208 << 20)                                          # -> non-temporal corpus loads (csrc/rq_api.hip)
+    idx.set_option("pipeline", 2)
+    idx.set_option("poison_cand", 1)
+    st = torch.cuda.Stream(device=dev)
+    plan = [(10, 0), (10, 0), (100, 0), (100, 0), (10, 1), (10, 0), (10, 0)]          # (k, metric) of consecutive calls
+    qs = [orc.synthetic_queries(64, 768, seed=4321 + i) * (3.0 if m == 1 else 1.0) for i, (k, m) in enumerate(plan)]
+    planted = [0, 63, 64, n // 2 - 1, n // 2, n - 1]
+    qs[1][: len(planted)] = np.stack([idx.get_rows_f16(p, 1)[0] for p in planted]).astype(np.float32)
+    outs = []
+    with torch.cuda.stream(st):
+        for (k, m), q in zip(plan, qs):
+            dq = torch.from_numpy(q).to(dev)
+            sc = torch.full((64, k), -7.0, device=dev); rw = torch.full((64, k), -7, device=dev, dtype=torch.int64)
+            stt = torch.full((64,), 9, device=dev, dtype=torch.int32)
+            idx.search_device(dq, 64, k, m, sc, rw, None, stt, st.cuda_stream)
+            outs.append((dq, sc, rw, stt))
+        idx.search_flush_device(st.cuda_stream)
+    st.synchronize()
+    t = idx.timing()
+    assert t["widened"] == 0 and t["exact_scans"] == 0
+    x16 = idx.get_rows_f16(0, n)
+    cos = orc.exact_scores(np.concatenate([q for q, (k, m) in zip(qs, plan) if m == 0], 0), x16, 0)
+    ip = orc.exact_scores(np.concatenate([q for q, (k, m) in zip(qs, plan) if m == 1], 0), x16, 1)
+    ci = ii = 0
+    for (k, m), q, (dq, sc, rw, stt) in zip(plan, qs, outs):
+        if m == 0:
+            es, er = orc.topk_from_scores(cos[64 * ci: 64 * ci + 64], k); ci += 1
+        else:
+            es, er = orc.topk_from_scores(ip[64 * ii: 64 * ii + 64], k); ii += 1
+        assert int(stt.abs().sum()) == 0, f"k={k} metric={m}: status {stt.cpu().tolist()}"
+        got_r, got_s = rw.cpu().numpy(), sc.cpu().numpy()
+        assert np.array_equal(got_r, er), f"k={k} metric={m}: rows differ at {np.argwhere(got_r != er)[:4].tolist()}"
+        assert float(np.abs(got_s - es).max()) <= SCORE_TOL * (3.0 if m == 1 else 1.0)
+    assert outs[1][2][: len(planted), 0].cpu().tolist() == planted
+    idx.close()
+
+
 def test_nomic_bert_embedder_end_to_end_random_init():
     """BASELINE.json configs[3] shape: raw text -> PyTorch-ROCm NomicBert forward -> HIP search.  No weights are
     available offline, so the architecture runs with random weights (2 layers to keep the test quick) and a
