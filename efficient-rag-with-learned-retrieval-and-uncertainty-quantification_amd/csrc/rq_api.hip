@@ -3,8 +3,8 @@
 // One rq_index = one row shard resident on one MI355X.  Layout in HBM:
 //   x          [cap][768] fp16, cap % 64 == 0, rows >= n are zero      (the only large array)
 //   rownorm64  [cap]      fp64 L2 norm of the stored row               (exact re-score)
-//   inv_norm   [cap]      fp32 1/norm, 0 for zero rows and pad rows     (scan, cosine)
-//   ones       [cap]      fp32 1.0 for rows < n, 0 beyond              (scan, inner product; lazy)
+//   inv_norm   [cap]      fp32 1/norm, 0 for zero rows, NaN for pad rows (scan, cosine)
+//   ones       [cap]      fp32 1.0 for rows < n, NaN beyond             (scan, inner product; lazy)
 // plus one workspace per stream (query fragments, per-bin scan records, bin keys, candidate keys).
 #include <hip/hip_runtime.h>
 
@@ -95,12 +95,12 @@ struct rq_index {
     float* inv_norm = nullptr;
     float* ones = nullptr;
     int64_t ones_valid = 0;
-    double* d_maxnorm = nullptr;   // device scalar, bits of the running max row norm
-    double max_row_norm = 0.0;
+    double* d_maxnorm = nullptr;   // device: bits of the running maxima {row norm, relative, absolute fp16-subnormal mass of a row}
+    double max_row_norm = 0.0, max_sub_rel = 0.0, max_sub_abs = 0.0;
     unsigned long long* dbg_stamps = nullptr;   // development (rq_debug_stamps)
     uint64_t scan_seq = 0;         // scan launches seen while profile = 1 (every profile_stride-th one is timed)
     // options
-    int ring = 3, prefetch = 1, kstage = 2, wide_batch = 1, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, profile_stride = 1, scan_nostore = 0, fast_tail = 1, pipeline = 0, tail_stop = 0, poison_cand = 0;
+    int ring = 3, prefetch = 1, kstage = 2, wide_batch = 1, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, profile_stride = 1, scan_nostore = 0, fast_tail = 1, pipeline = 0, tail_stop = 0, poison_cand = 0, wide128 = 0, wide256 = 2;
     double eps = -1.0;
     std::map<hipStream_t, StreamCtx> ctx;
     hipStream_t own_stream = nullptr;
@@ -118,14 +118,27 @@ struct rq_index {
 // Derived bound on |approximate scan score - exact score| for unit queries and cosine scaling:
 //   fp16 rounding of the unit query (2^-11 relative, 2^-25 absolute in the subnormal range),
 //   fp32 accumulation inside the MFMA chain (<= 4 * 768 * 2^-24 of sum|q_i x_i| <= 1, conservative),
-//   two fp32 roundings for the row scale.  See DESIGN.md "certificate".
+//   two fp32 roundings for the row scale,
+//   2^-17 relative for the row position that rq_scan_wide.hip writes into the 6 low mantissa bits of a score
+//   (4.88e-4 + 8e-7 + 1.83e-4 + 1.2e-7 + 7.6e-6 = 6.8e-4).  See DESIGN.md "certificate".
 static const float RQ_EPS_DEFAULT = 7.0e-4f;
+
+// Bound on |scan score - exact score| handed to the tail kernels, which use it as is for cosine and multiplied by the
+// largest row norm for the inner product: the derived bound (or option "eps") plus what the matrix cores drop by flushing
+// the fp16-subnormal elements of a stored row (rq_select.hip rq_rownorm_kernel).
+static float scan_eps(const rq_index* idx, int metric) {
+    const double base = idx->eps < 0 ? (double)RQ_EPS_DEFAULT : idx->eps;
+    if (metric == RQ_METRIC_COSINE) return (float)(base + idx->max_sub_rel * (1.0 + 1e-6));
+    return (float)(base + (idx->max_row_norm > 0.0 ? idx->max_sub_abs / idx->max_row_norm * (1.0 + 1e-6) : 0.0));
+}
+// Beyond this bound the approximate pass cannot narrow anything down (cosine scores live in [-1, 1]): scan exactly.
+static const float RQ_EPS_USELESS = 0.05f;
 
 static int nb_default(const rq_index* idx, int k) {
     const int slack = idx->slack_bins >= 0 ? idx->slack_bins : std::max(8, k / 8);
     return k + slack;
 }
-static const int RQ_NB_MAX = 3071;   // select kernel: m = nb + 1 <= RQ_SEL_L - RQ_SEL_THREADS
+static const int RQ_NB_MAX = 3071;
 
 static int use_device(const rq_index* idx) {
     HIPCHK(hipSetDevice(idx->device));
@@ -163,7 +176,9 @@ static int grow(rq_index* idx, int64_t want_rows) {
     }
     HIPCHK(hipMemsetAsync(nx + (size_t)keep * RQ_DPAD * 2, 0, (size_t)(cap - keep) * RQ_DPAD * 2, idx->own_stream));
     HIPCHK(hipMemsetAsync(nn + keep, 0, (size_t)(cap - keep) * sizeof(double), idx->own_stream));
-    HIPCHK(hipMemsetAsync(ni + keep, 0, (size_t)(cap - keep) * sizeof(float), idx->own_stream));
+    // row scales of the pad rows are NaN (0xffffffff): their scan scores sort last without a per-score row test
+    // (rq_scan_wide.hip); rq_scan.hip masks rows >= n on its own
+    HIPCHK(hipMemsetAsync(ni + keep, 0xff, (size_t)(cap - keep) * sizeof(float), idx->own_stream));
     HIPCHK(hipStreamSynchronize(idx->own_stream));
     if (idx->x) (void)hipFree(idx->x);
     if (idx->rownorm64) (void)hipFree(idx->rownorm64);
@@ -198,8 +213,8 @@ extern "C" rq_index* rq_index_create(int dim, int n_devices, const int* device_i
     }
     idx->cu_count = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&idx->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc((void**)&idx->d_maxnorm, sizeof(double)) != hipSuccess ||
-        hipMemset(idx->d_maxnorm, 0, sizeof(double)) != hipSuccess) {
+        hipMalloc((void**)&idx->d_maxnorm, 3 * sizeof(double)) != hipSuccess ||
+        hipMemset(idx->d_maxnorm, 0, 3 * sizeof(double)) != hipSuccess) {
         set_err(RQ_EHIP, "device setup failed on device %d", idx->device);
         delete idx;
         return nullptr;
@@ -249,22 +264,15 @@ extern "C" int rq_index_reserve(rq_index* idx, int64_t n_rows) {
 }
 
 // ---- append ----------------------------------------------------------------------------------
-__global__ void rq_maxnorm_kernel(const double* norm64, int64_t b, int64_t e, unsigned long long* out) {
-    double m = 0.0;
-    for (int64_t i = b + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e; i += (int64_t)gridDim.x * blockDim.x) m = fmax(m, norm64[i]);
-    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(m));   // non-negative doubles order as integers
-}
-
 static int finish_add(rq_index* idx, int64_t n_new) {
     hipStream_t s = idx->own_stream;
     const int64_t b = idx->n, e = idx->n + n_new;
-    HIPCHK(rq_rownorm_launch(idx->x, b, e, idx->rownorm64, s));
+    HIPCHK(rq_rownorm_launch(idx->x, b, e, idx->rownorm64, (unsigned long long*)idx->d_maxnorm, s));
     HIPCHK(rq_rowscale_launch(idx->rownorm64, b, e, idx->inv_norm, s));
-    hipLaunchKernelGGL(rq_maxnorm_kernel, dim3(256), dim3(256), 0, s, (const double*)idx->rownorm64, b, e, (unsigned long long*)idx->d_maxnorm);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(&idx->max_row_norm, idx->d_maxnorm, sizeof(double), hipMemcpyDeviceToHost, s));
+    double st[3] = {0.0, 0.0, 0.0};
+    HIPCHK(hipMemcpyAsync(st, idx->d_maxnorm, sizeof(st), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    idx->max_row_norm = st[0]; idx->max_sub_rel = st[1]; idx->max_sub_abs = st[2];
     idx->n = e;
     if ((uint64_t)(idx->row_offset + idx->n) >= 0xffffffffull) return set_err(RQ_EUNSUPPORTED, "row ids beyond 2^32-1 are not supported");
     return RQ_OK;
@@ -330,7 +338,9 @@ extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     if (!idx || !name) return set_err(RQ_EINVAL, "bad option call");
     const std::string s(name);
     if (s == "ring") { if (v < 2 || v > 6) return set_err(RQ_EINVAL, "ring must be 2..6"); idx->ring = (int)v; }
-    else if (s == "wide_batch") idx->wide_batch = (int)v;
+    else if (s == "wide_batch") { if (v < 0 || v > 3) return set_err(RQ_EINVAL, "wide_batch must be 0..3"); idx->wide_batch = (int)v; }
+    else if (s == "wide128") { if (v < 0 || v > 92) return set_err(RQ_EINVAL, "wide128: a 128-query variant of csrc/rq_scan_wide.hip"); idx->wide128 = (int)v; }
+    else if (s == "wide256") { if (v < 0 || v > 92) return set_err(RQ_EINVAL, "wide256: a 256-query variant of csrc/rq_scan_wide.hip"); idx->wide256 = (int)v; }
     else if (s == "kstage") { if (v != 1 && v != 2) return set_err(RQ_EINVAL, "kstage must be 1 or 2"); idx->kstage = (int)v; }
     else if (s == "prefetch") { if (v != 1 && v != 4 && v != 6 && v != 12) return set_err(RQ_EINVAL, "prefetch must be 1, 4, 6 or 12"); idx->prefetch = (int)v; }
     else if (s == "wg_per_cu") { if (v < 1 || v > 8) return set_err(RQ_EINVAL, "wg_per_cu must be 1..8"); idx->wg_per_cu = (int)v; }
@@ -358,13 +368,17 @@ extern "C" double rq_get_option(const rq_index* idx, const char* name) {
     if (s == "wg_per_cu") return idx->wg_per_cu;
     if (s == "nt") return idx->nt;
     if (s == "slack_bins") return idx->slack_bins;
-    if (s == "eps") return idx->eps < 0 ? RQ_EPS_DEFAULT : idx->eps;
+    if (s == "eps") return idx->eps < 0 ? RQ_EPS_DEFAULT : idx->eps;   // the base bound; "eps_cosine" / "eps_ip": with the shard's flush term
     if (s == "profile") return idx->profile;
     if (s == "fast_tail") return idx->fast_tail;
     if (s == "pipeline") return idx->pipeline;
     if (s == "profile_stride") return idx->profile_stride;
     if (s == "cu_count") return idx->cu_count;
     if (s == "max_row_norm") return idx->max_row_norm;
+    if (s == "max_sub_rel") return idx->max_sub_rel;   // largest share of a row's norm that sits in fp16-subnormal elements
+    if (s == "max_sub_abs") return idx->max_sub_abs;
+    if (s == "eps_cosine") return scan_eps(idx, RQ_METRIC_COSINE);
+    if (s == "eps_ip") return scan_eps(idx, RQ_METRIC_IP);
     return NAN;
 }
 
@@ -415,8 +429,8 @@ static int ensure_ws(Workspace& w, int bpad, int64_t stride, int64_t m, size_t c
 static int ensure_ones(rq_index* idx, hipStream_t s) {
     if (idx->ones && idx->ones_valid == idx->n) return RQ_OK;
     if (!idx->ones) HIPCHK(hipMalloc((void**)&idx->ones, (size_t)idx->cap * sizeof(float)));
-    std::vector<float> h((size_t)idx->cap, 0.f);
-    std::fill(h.begin(), h.begin() + idx->n, 1.f);
+    std::vector<float> h((size_t)idx->cap, std::nanf(""));   // pad rows: NaN, like inv_norm (see grow)
+    std::fill(h.begin(), h.begin() + idx->n, RQ_QSCALE_INV);  // the queries carry 2^12 (rq_select.hip)
     HIPCHK(hipMemcpy(idx->ones, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
     idx->ones_valid = idx->n;
     return RQ_OK;
@@ -476,12 +490,28 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     const int nquads = (int)((idx->n + 63) / 64);
     const int64_t nbins = nquads;   // bin = quad
     // tiny shards (fewer than two bins per wanted bin): the approximate pass cannot narrow anything down
-    const bool exact = nb < 0 || 2 * (int64_t)nb >= nbins;
+    // ... and shards whose rows keep so much of their norm in fp16-subnormal elements that the scan's scores say nothing
+    const bool exact = nb < 0 || 2 * (int64_t)nb >= nbins || (idx->eps < 0 && scan_eps(idx, metric) > RQ_EPS_USELESS);
     if (exact) nb = (int)std::min<int64_t>(nbins, INT32_MAX / 64);
     if (!exact && nb > RQ_NB_MAX) return set_err(RQ_EINVAL, "nb %d too large", nb);
-    // queries per corpus pass: 128 (8 waves per workgroup, one workgroup per CU) once a call has more than 64
-    const int qb = (idx->wide_batch && B > 64) ? 128 : 64;
-    const int bpad = (B + qb - 1) / qb * qb;
+    // Queries per corpus pass: 64, or -- once a call has more than 64 -- 128 / 256 (every LDS fragment of the corpus feeds
+    // two MFMAs per wave; option "wide_batch": 0 = passes of 64 only, 1 = 64/128/256, 2 = round 1's 8-wave 128-query pass,
+    // 3 = 64/128 without the 256-query pass).  A call is cut into passes greedily: 256 while more than 128 queries remain,
+    // then 128, then 64.
+    int pass_q[1024], npass = 0, bpad = 0;
+    {
+        const int wb = idx->wide_batch;
+        const int big = wb == 1 ? 256 : (wb == 2 || wb == 3 ? 128 : 64);
+        for (int left = B; left > 0;) {
+            int qb = 64;
+            if (big >= 256 && left > 128) qb = 256;
+            else if (big >= 128 && left > 64) qb = 128;
+            if (npass == 1024) return set_err(RQ_EINVAL, "too many passes");
+            pass_q[npass++] = qb;
+            bpad += qb;
+            left -= qb;
+        }
+    }
     const int64_t stride = (nbins + 63) / 64 * 64;
     const int m = nb + 1;   // generic tail: bins re-scored + the first one that is not
     const bool fast = !exact && !force_generic && idx->fast_tail && k <= RQ_FAST_MAX_K;
@@ -490,6 +520,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     const bool piped = fast && may_defer && idx->pipeline == 1;
     // fused mode: one scan launch per call (<= 64 queries), which carries the tail of the previous call
     const bool fused = fast && may_defer && idx->pipeline == 2 && bpad == 64;
+    const int qb0 = pass_q[0];
     int par = 0;
     if (fused) {
         par = (int)(cx.calls++ & 1);
@@ -523,23 +554,25 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     }
     // unit-norm fp16 query fragments for the scan (+ padded fp32 queries / fp64 norms for the generic tail)
     HIPCHK(rq_prep_queries_launch(d_q, idx->dim, B, bpad, w.qh, w.q32, w.qn, s));
-    const int grid = (int)std::min<int64_t>(std::min<int64_t>(nquads, RQ_WGMAX_STRIDE),
-                                            (int64_t)idx->cu_count * (qb == 128 ? 1 : idx->wg_per_cu));
+    // one scan grid for every pass of the call (the tail reads nwg partition maxima per query): the widest pass decides
+    const int wg_cu = qb0 > 64 ? 1 : idx->wg_per_cu;   // every pass of more than 64 queries runs one 512-thread workgroup per CU
+    const int grid = (int)std::min<int64_t>(std::min<int64_t>(nquads, RQ_WGMAX_STRIDE), (int64_t)idx->cu_count * wg_cu);
     if (!exact) {
         // non-temporal loads only for shards that cannot stay in the 256 MiB Infinity Cache between two scans
         // (measured: 192 MB shard 36 us with default policy vs 39 us nt; 1.5 GB shard 250 us nt vs 285 us default)
         const bool nt = idx->nt < 0 ? (idx->n * (int64_t)(RQ_DPAD * 2) > ((int64_t)208 << 20)) : idx->nt != 0;
-        for (int blk = 0; blk < bpad / qb; ++blk) {
+        for (int blk = 0, q0 = 0; blk < npass; q0 += pass_q[blk], ++blk) {
+            const int qb = pass_q[blk];
             RqScanArgs a;
             a.x = idx->x;
             a.row_scale = scale;
-            a.qh = w.qh + (size_t)blk * qb * RQ_DPAD;
-            a.bins = w.bins + (size_t)blk * qb * w.bins_stride;
+            a.qh = w.qh + (size_t)q0 * RQ_DPAD;
+            a.bins = w.bins + (size_t)q0 * w.bins_stride;
             a.bins_stride = w.bins_stride;
             a.n_rows = idx->n;
             a.nquads = nquads;
-            a.nq_valid = idx->scan_nostore == 1 ? 0 : std::min(qb, B - blk * qb);
-            a.wgmax = w.wgmax + (size_t)blk * qb * RQ_WGMAX_STRIDE;
+            a.nq_valid = idx->scan_nostore == 1 ? 0 : std::min(qb, B - q0);
+            a.wgmax = w.wgmax + (size_t)q0 * RQ_WGMAX_STRIDE;
             a.wgmax_stride = RQ_WGMAX_STRIDE;
             const bool prof = idx->profile == 1 && idx->ev_used < 16384 && (idx->scan_seq++ % (uint64_t)idx->profile_stride) == 0;
             if (prof) {
@@ -561,7 +594,9 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
                 } else
                 HIPCHK(rq_scan_tail_launch(a, cx.fused_tail, cx.fused_B, nt, grid, s));
             } else if (fused) HIPCHK(rq_scan_launch(a, 3, 1, 2, 4, nt, grid, s));
-            else if (qb == 128) HIPCHK(rq_scan_launch(a, 3, 4, 1, 8, nt, grid, s));
+            else if (qb == 256) HIPCHK(rq_scan_wide_launch(a, idx->wide256, 256, nt, grid, s));
+            else if (qb == 128 && idx->wide_batch == 2) HIPCHK(rq_scan_launch(a, 3, 4, 1, 8, nt, grid, s));   // round 1's 8-wave pass
+            else if (qb == 128) HIPCHK(rq_scan_wide_launch(a, idx->wide128, 128, nt, grid, s));
             else HIPCHK(rq_scan_launch(a, idx->ring, idx->prefetch, idx->kstage, 4, nt, grid, s));
             if (prof) { HIPCHK(hipEventRecord(idx->events[idx->ev_used].second, s)); idx->ev_used++; }
         }
@@ -577,7 +612,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             ta.bins = w.bins; ta.bins_stride = w.bins_stride; ta.nbins = nbins;
             ta.wgmax = w.wgmax; ta.wgmax_stride = RQ_WGMAX_STRIDE; ta.nwg = grid;
             ta.m = (int)std::min<int64_t>(k, idx->n); ta.metric = metric; ta.k = k;
-            ta.eps = idx->eps < 0 ? RQ_EPS_DEFAULT : (float)idx->eps;
+            ta.eps = scan_eps(idx, metric);
             ta.max_row_norm = (float)(idx->max_row_norm * (1.0 + 1e-6)); ta.row_offset = idx->row_offset;
             ta.cand = w.cand; ta.rowcount = w.rowcount; ta.done = w.done; ta.ovf = w.ovf;
             ta.out_scores = d_scores; ta.out_rows = d_rows; ta.out_keys = d_keys; ta.out_status = d_status;
@@ -616,7 +651,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     HIPCHK(rq_rescore_launch(ra, B, s));
     RqFinalArgs fa;
     fa.cand = w.cand; fa.ncand = (int)ncand; fa.binkeys = w.binkeys; fa.binkeys_stride = m; fa.nb = nb; fa.nbins = exact ? nb : nbins;
-    fa.qnorm64 = w.qn; fa.metric = metric; fa.eps = idx->eps < 0 ? RQ_EPS_DEFAULT : (float)idx->eps;
+    fa.qnorm64 = w.qn; fa.metric = metric; fa.eps = scan_eps(idx, metric);
     fa.max_row_norm = (float)(idx->max_row_norm * (1.0 + 1e-6)); fa.k = k; fa.row_offset = idx->row_offset; fa.n_rows = idx->n;
     fa.out_scores = d_scores; fa.out_rows = d_rows; fa.out_keys = d_keys; fa.out_status = d_status;
     HIPCHK(rq_final_launch(fa, B, s));

@@ -15,6 +15,8 @@
 #define RQ_DPAD 768            // padded row length the kernels are specialised for
 #define RQ_QBLOCK 64           // queries scored per corpus pass
 #define RQ_QUAD_ROWS 64
+#define RQ_QSCALE 4096.0f             // unit queries are scaled by 2^12 before their fp16 rounding (fp16 subnormal flush of the
+#define RQ_QSCALE_INV 0.000244140625f // matrix cores, rq_select.hip); the scan's row scales carry 2^-12
 #define RQ_TILE_ROWS 16
 
 typedef _Float16 rq_half8 __attribute__((ext_vector_type(8)));

@@ -8,6 +8,11 @@
 #include "rq_device.h"
 #include "rq_kernels.h"   // RQ_CAND_CAP
 
+// The score definition divides by (|q| |x| + 1e-30); the scan scores the pure cosine.  A stored fp16 row has norm 0 or
+// >= 6e-8, so for |q| >= 2e-17 the two differ by less than 1e-6 relative on every row; a query below that is never
+// certified from the approximate pass and takes the exact fp64 route (rq_search_fixup_device), which follows the definition.
+#define RQ_TINY_QUERY_NORM 2e-17
+
 struct RqFinalLds {
     uint64_t skeys[2048];
     uint64_t wbest[2][4];
@@ -109,6 +114,7 @@ __device__ __forceinline__ void rq_final_body(const RqFinalCore& a, int total, i
         // (unit-query units).  Exact iff that bound is strictly below the k-th exact score.
         int good;
         if (total > RQ_CAND_CAP || overflow) good = 0;                  // some candidate row was not re-scored
+        else if (a.metric == 0 && qn < RQ_TINY_QUERY_NORM) good = 0;                     // the 1e-30 of the score definition is no longer negligible
         else if (T == -__builtin_huge_valf()) good = have >= kk;        // every row was a candidate
         else if (have < kk || kth == 0) good = 0;
         else {

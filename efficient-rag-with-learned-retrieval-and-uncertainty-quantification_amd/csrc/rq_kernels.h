@@ -5,8 +5,8 @@
 
 struct RqScanArgs {
     const void* x;            // fp16 corpus shard [rows_padded][768], rows_padded % 64 == 0, pad rows zero
-    const float* row_scale;   // [rows_padded] 1/||row|| (cosine) or 1.0 (inner product); pad entries 0
-    const _Float16* qh;       // [QB][768] unit-norm fp16 queries of this block (QB = 64 or 128), unused slots zero
+    const float* row_scale;   // [rows_padded] 2^-12 / ||row|| (cosine) or 2^-12 (inner product); pad entries NaN
+    const _Float16* qh;       // [QB][768] fp16(q / ||q|| * 2^12) of this block (QB = 64, 128 or 256), unused slots zero
     uint2* bins;              // [QB][bins_stride] per (query, quad) record, see rq_device.h
     int64_t bins_stride;      // records per query row, >= nquads
     int64_t n_rows;           // valid rows of the shard
@@ -19,8 +19,14 @@ struct RqScanArgs {
 
 hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int ks, int qw, bool nt, int grid, hipStream_t stream);
 
-// Row statistics at add time: row_norm64[i] = sqrt(sum x^2) in fp64, row_scale[i] = (float)(1/norm) or 0.
-hipError_t rq_rownorm_launch(const void* x, int64_t row_begin, int64_t row_end, double* norm64, hipStream_t stream);
+// Passes of 128 / 256 queries (rq_scan_wide.hip): one 512-thread workgroup per CU, LDS reads running ahead of the MFMAs
+// across stage boundaries, v_med3 selection.  Returns hipErrorInvalidValue for a variant that is not built or does not
+// score `queries` queries per pass.
+hipError_t rq_scan_wide_launch(const RqScanArgs& a, int variant, int queries, bool nt, int grid, hipStream_t stream);
+
+// Row statistics at add time: row_norm64[i] = sqrt(sum x^2) in fp64; stats[3] (device, running maxima as double bits):
+// largest norm, largest relative and absolute mass of fp16-subnormal elements in a row (see rq_select.hip).
+hipError_t rq_rownorm_launch(const void* x, int64_t row_begin, int64_t row_end, double* norm64, unsigned long long* stats, hipStream_t stream);
 
 // fp32 rows (device) -> fp16 rows, optionally L2-normalised first (see include/rq.h rq_index_add_f32).
 hipError_t rq_convert_f32_launch(const float* src, int dim, int64_t n, int normalize, void* dst_rows_f16, hipStream_t stream);

@@ -1,0 +1,337 @@
+// rq_scan_wide.hip -- the corpus scan for passes of MORE than 64 queries (128 per pass): same arithmetic, records and
+// contracts as rq_scan.hip (which keeps the 64-query headline kernel), different schedule.
+//
+// Why a second schedule.  With 128 queries per pass every corpus byte feeds twice the matrix work, so a CU has to issue
+// 2 x the MFMAs and LDS fragment reads per HBM byte while still streaming at the HBM rate.  rq_scan.hip's loop is
+// "wait for the stage, barrier, then for every fragment: ds_read -> wait -> MFMA": the LDS latency of the first
+// fragments after every barrier and of every read group is exposed, all waves of the (single) workgroup of a CU hit it at
+// the same moment, and round 1's 8-wave variant measured 332-355 us per 128-query pass at 1M rows against 240 us for
+// the 64-query pass (1.45x per corpus byte instead of 2x).  Here:
+//   * a stage is one TILE (16 whole rows, 24 KiB, contiguous in HBM); the ring has 4 slots = the 4 tiles of a quad, so
+//     every LDS address in the unrolled quad loop is static;
+//   * the LDS fragment reads run D fragments ahead of the MFMAs in one continuous stream that does NOT stop at stage
+//     boundaries: a stage is acquired (counted vmcnt for the wave's own LDS-DMA pieces, one raw s_barrier) when the READ
+//     pointer enters it, i.e. D fragments before the MFMA pointer leaves the previous one, so the barrier and the first
+//     reads of a stage hide under the MFMAs of the stage before;
+//   * the slot refilled at that barrier is the one of the stage two back (fully consumed by every wave), which keeps two
+//     stages (48 KiB per CU) in flight like the 64-query kernel does with its two workgroups per CU;
+//   * QG = 2: a wave keeps 2 x 16 queries in registers (192 VGPRs, one wave per SIMD) and every fragment it reads feeds
+//     two MFMAs -- half the LDS reads per query of the 8-wave form.
+// Replaces the arithmetic of reference rag_uq/streaming_index.py:355-359 (collection.query), like rq_scan.hip.
+#include "rq_device.h"
+#include "rq_kernels.h"
+
+extern __shared__ __attribute__((aligned(16))) char rq_smem_w[];
+
+typedef __attribute__((address_space(3))) void* lds_ptr_w;
+typedef const __attribute__((address_space(1))) void* glb_ptr_w;
+
+template <int N>
+__device__ __forceinline__ void rqw_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// records per query parked in LDS before they are written out (32 KiB of staging for 128 queries, 32 KiB for 256)
+__host__ __device__ static constexpr int rqw_sq(int QW, int QG) { return QW * QG >= 16 ? 16 : 32; }
+
+// NT: non-temporal corpus loads; D: fragments the LDS reads run ahead of the MFMAs (2..12);
+// QW: waves per workgroup; QG: 16-query groups per wave.  Queries per pass = 16 * QW * QG.
+// EPI: 1 = the selection keeps the row position in the 6 low mantissa bits of the score (v_med3 inserts, 6 VALU per score),
+//      0 = rq_scan.hip's compare/select form (14 VALU per score).
+// DBG (timing experiments only, results invalid): 1 = no selection epilogue, 2 = no LDS fragment reads, 3 = no MFMAs
+__device__ __forceinline__ float rqw_med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+// Insert x into the sorted triple m1 >= m2 >= m3: exactly three VALU instructions.  Written as asm because the compiler
+// turns fmaxf / fmed3(a, b, +inf) on a value that went through integer bit operations into canonicalise + v_max (two
+// instructions); x and the triple are never NaN here (scores are clamped to the finite range before their bits are touched).
+__device__ __forceinline__ void rqw_insert(float& m1, float& m2, float& m3, float x) {
+    float n3, n2, n1;
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(n3) : "v"(m2), "v"(m3), "v"(x));
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(n2) : "v"(m1), "v"(m2), "v"(x));
+    asm("v_max_f32 %0, %1, %2" : "=v"(n1) : "v"(m1), "v"(x));
+    m3 = n3; m2 = n2; m1 = n1;
+}
+
+template <bool NT, int D, int QW, int QG, int EPI, int DBG = 0>
+__device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, const int G) {
+    static_assert(D >= 2 && D <= 12 && 24 % D == 0, "prefetch distance");
+    static_assert(QW == 4 || QW == 8, "waves per workgroup");
+    static_assert(QG == 1 || QG == 2, "query groups per wave");
+    constexpr int STAGE_BYTES = 24576;             // 16 rows x 1536 B
+    constexpr int DPW = 24 / QW;                   // LDS-DMA wave-instructions (1 KiB each) per wave per stage
+    constexpr int VM_KEEP = DPW;                   // at an acquire, the wave's pieces of the NEXT stage may stay in flight
+    constexpr unsigned AUX = NT ? 2u : 0u;
+    constexpr int SQ = rqw_sq(QW, QG);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kg = lane >> 4;          // k-group of the MFMA operand / row group of the result
+    const int r16 = lane & 15;         // corpus row inside the tile (A operand), query inside the group (D)
+
+    // per-lane DMA source offsets: LDS chunk p = 64*j + lane of a stage holds row r = p / 96, source chunk (p % 96) ^ r
+    unsigned voff[DPW];
+#pragma unroll
+    for (int i = 0; i < DPW; ++i) {
+        const int p = 64 * (wave * DPW + i) + lane;
+        const int r = p / 96, cp = p % 96;
+        voff[i] = (unsigned)(r * (RQ_DPAD * 2) + ((cp ^ r) << 4));
+    }
+    // per-lane LDS read offset of k-step s: (rbase0 ^ ((s & 3) << 6)) + ((s & ~3) << 6)   (see rq_scan.hip)
+    const unsigned rbase0 = (unsigned)(r16 * 1536 + ((kg ^ (r16 & 3)) << 4) + ((r16 >> 2) << 6));
+
+    const int q_lo = (int)((int64_t)b * a.nquads / G);
+    const int nloc = (int)((int64_t)(b + 1) * a.nquads / G) - q_lo;
+    const int nst = nloc * 4;          // stages = tiles of this workgroup's quads
+    const char* xb = (const char*)a.x;
+    char* norm_lds = rq_smem_w + 4 * STAGE_BYTES;                // [2 parities][64 row scales]
+    uint2* const stg = (uint2*)(norm_lds + 512);                 // [16 * QW * QG queries][SQ] finished records
+
+    // stage gs = tile (gs & 3) of local quad (gs >> 2) -> ring slot (gs & 3).  Stages are issued strictly in order, so the
+    // source addresses are two running (wave-uniform) pointers instead of 64-bit multiplications per stage.
+    const char* gnext = xb + (int64_t)q_lo * (RQ_QUAD_ROWS * RQ_DPAD * 2);           // corpus bytes of the next stage
+    const float* nsnext = a.row_scale + (int64_t)q_lo * RQ_QUAD_ROWS + lane;       // row scales of the next quad
+    auto issue = [&](int gs) {
+        const int t = gs & 3;
+        char* l = rq_smem_w + t * STAGE_BYTES + (wave * DPW) * 1024;
+#pragma unroll
+        for (int i = 0; i < DPW; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_w)(gnext + voff[i]), (lds_ptr_w)(l + i * 1024), 16, 0, AUX);
+        gnext += STAGE_BYTES;
+        if (t == 0) {   // row scales of the quad (256 B); visible to all waves after wave 0's wait + a barrier
+            if (wave == 0) __builtin_amdgcn_global_load_lds((glb_ptr_w)nsnext, (lds_ptr_w)(norm_lds + (((gs >> 2) & 1) << 8)), 4, 0, 0);
+            nsnext += RQ_QUAD_ROWS;
+        }
+    };
+    // the read pointer enters stage gs: its bytes must have landed for every wave; the slot of stage gs - 2 is free
+    auto acquire = [&](int gs) {
+        if (gs + 1 < nst) rqw_wait_vmcnt<VM_KEEP>(); else rqw_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (gs + 2 < nst) issue(gs + 2);
+    };
+
+    issue(0);
+    if (nst > 1) issue(1);
+
+    const float NEG_INF = -__builtin_huge_valf();
+    float wmax[QG];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) wmax[g] = NEG_INF;
+
+    // query fragments: B[k = 8*kg + j][col = r16] of k-step s == qh[16*(QG*wave + g) + r16][32*s + 8*kg + j]
+    rq_half8 qf[QG][24];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        const rq_half8* qsrc = (const rq_half8*)(a.qh + (size_t)(16 * (QG * wave + g) + r16) * RQ_DPAD + 8 * kg);
+#pragma unroll
+        for (int s = 0; s < 24; ++s) qf[g][s] = qsrc[4 * s];
+#pragma unroll
+        for (int s = 0; s < 24; ++s) asm volatile("" : "+v"(qf[g][s]));   // ordinary loads retired before the main loop
+    }
+
+    auto frag = [&](int t, int s) -> rq_half8 {
+        if (DBG == 2) { rq_half8 z; asm volatile("" : "=v"(z)); return z; }
+        return *(const rq_half8*)(rq_smem_w + t * STAGE_BYTES + (rbase0 ^ (unsigned)((s & 3) << 6)) + ((s & ~3) << 6));
+    };
+    auto flush = [&](int quad0, int count) {
+        // each wave writes the rows of its own 16 QG queries: 64 / SQ queries x SQ records (8 SQ-byte runs) per instruction
+        constexpr int QPI = 64 / SQ;
+#pragma unroll 1
+        for (int i = 0; i < 16 * QG / QPI; ++i) {
+            const int ql = 16 * QG * wave + QPI * i + lane / SQ, j = lane & (SQ - 1);
+            if (j < count && ql < a.nq_valid) a.bins[(int64_t)ql * a.bins_stride + quad0 + j] = stg[ql * SQ + j];
+        }
+    };
+
+    rq_half8 av[D];   // fragment ring: fragment f of the quad lives in av[f % D]
+    acquire(0);
+#pragma unroll
+    for (int f = 0; f < D; ++f) av[f] = frag(0, f);
+
+    for (int lq = 0; lq < nloc; ++lq) {
+        const int quad = q_lo + lq;
+        const bool more = lq + 1 < nloc;
+        float m1[QG], m2[QG], m3[QG];   // the three largest approximate scores of the lane's 16 rows, per query group
+        uint32_t ap[QG];                // rows (0..63) of the largest [7:0] and second largest [15:8]
+#pragma unroll
+        for (int g = 0; g < QG; ++g) { m1[g] = NEG_INF; m2[g] = NEG_INF; m3[g] = NEG_INF; ap[g] = 0; }
+        const char* nrow = norm_lds + ((lq & 1) << 8) + kg * 16;
+        rq_float4 acc[QG];
+#pragma clang loop unroll(full)
+        for (int t = 0; t < 4; ++t)
+#pragma clang loop unroll(full)
+        for (int s = 0; s < 24; ++s) {
+            const int f = t * 24 + s;
+            const rq_half8 cur = av[f % D];
+            // the read pointer: fragment f + D, D fragments ahead, crossing stage (and quad) boundaries
+            {
+                const int r = f + D;
+                if (r < 96) {
+                    if (r % 24 == 0) acquire(lq * 4 + r / 24);
+                    av[f % D] = frag(r / 24, r % 24);
+                } else {
+                    // the next quad's first fragments; after the workgroup's last quad the reads still run (unconditional
+                    // code, no copies) on bytes nobody uses: nothing is in flight into slot 0 any more
+                    if (r == 96 && more) acquire(lq * 4 + 4);
+                    av[f % D] = frag(0, r - 96);
+                }
+            }
+            if (s == 0) {
+#pragma unroll
+                for (int g = 0; g < QG; ++g) acc[g] = rq_float4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (DBG == 3) {
+#pragma unroll
+                for (int g = 0; g < QG; ++g) asm volatile("" : "+v"(acc[g]) : "v"(cur), "v"(qf[g][s]));
+            } else {
+#pragma unroll
+            for (int g = 0; g < QG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur, qf[g][s], acc[g], 0, 0, 0);
+            }
+            if (s == 23 && DBG == 1) {
+#pragma unroll
+                for (int g = 0; g < QG; ++g) m1[g] = fmaxf(m1[g], fmaxf(fmaxf(acc[g][0], acc[g][1]), fmaxf(acc[g][2], acc[g][3])));
+            }
+            if (s == 23 && DBG != 1 && EPI == 1) {
+                // Tile epilogue, D[row = 4*kg + i][query = r16].  score = acc * row scale, clamped to the finite range (an
+                // infinite score stays the largest, NaN becomes the smallest); its 6 low mantissa bits are then REPLACED by
+                // the row's position in the quad (bits 4..5 tile, 0..1 register; the lane's row group 4*kg is OR-ed in
+                // after the quad), so the three v_med3 inserts carry the positions along: 6 VALU per score and no
+                // data-dependent code.  The perturbation (< 64 ulp, 7.6e-6 relative) is part of the scan's error bound
+                // eps; every field of the record written below stays an UPPER bound of the unperturbed score.
+                // Rows beyond the shard's end carry a NaN row scale (rq_api.hip) and therefore sort last.
+                const rq_float4 nv = *(const rq_float4*)(nrow + t * 64);
+#pragma unroll
+                for (int g = 0; g < QG; ++g)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float sc = rqw_med3(acc[g][i] * nv[i], -3.4028234664e38f, 3.4028234664e38f);
+                        const float x = __uint_as_float((__float_as_uint(sc) & 0xffffffc0u) | (uint32_t)(t * 16 + i));
+                        rqw_insert(m1[g], m2[g], m3[g], x);
+                    }
+            }
+            if (s == 23 && DBG != 1 && EPI == 0) {
+                // tile epilogue: D[row = 4*kg + i][query = r16]
+                const rq_float4 nv = *(const rq_float4*)(nrow + t * 64);
+                const int64_t row0 = (int64_t)quad * RQ_QUAD_ROWS + t * RQ_TILE_ROWS + 4 * kg;
+#pragma unroll
+                for (int g = 0; g < QG; ++g)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float sc = acc[g][i] * nv[i];
+                        sc = (row0 + i < a.n_rows) ? sc : NEG_INF;
+                        // comparisons are false for NaN: NaN scores are dropped.  Ties count as separate rows.
+                        const bool gt1 = sc > m1[g], gt2 = sc > m2[g];
+                        const uint32_t pos = (uint32_t)(t * 16 + i);
+                        m3[g] = gt2 ? m2[g] : fmaxf(m3[g], sc);
+                        ap[g] = gt1 ? ((ap[g] << 8) | pos) : (gt2 ? ((ap[g] & 0xffu) | (pos << 8)) : ap[g]);
+                        m2[g] = gt1 ? m1[g] : fmaxf(m2[g], sc);
+                        m1[g] = gt1 ? sc : m1[g];
+                    }
+            }
+        }
+        if (EPI == 1) {
+#pragma unroll
+            for (int g = 0; g < QG; ++g) {
+                // positions become complete (row group of the lane), then the four lanes that share the query merge their
+                // sorted triples: the other lane's three values are inserted one by one; all four lanes end up equal
+                const uint32_t kgb = (uint32_t)kg << 2;
+                float x1 = __uint_as_float(__float_as_uint(m1[g]) | kgb), x2 = __uint_as_float(__float_as_uint(m2[g]) | kgb),
+                      x3 = __uint_as_float(__float_as_uint(m3[g]) | kgb);
+#pragma unroll
+                for (int off = 16; off <= 32; off <<= 1) {
+                    const float o1 = __shfl_xor(x1, off, 64), o2 = __shfl_xor(x2, off, 64), o3 = __shfl_xor(x3, off, 64);
+                    rqw_insert(x1, x2, x3, o1);
+                    rqw_insert(x1, x2, x3, o2);
+                    rqw_insert(x1, x2, x3, o3);
+                }
+                asm("v_max_f32 %0, %1, %2" : "=v"(wmax[g]) : "v"(wmax[g]), "v"(x1));
+                if (kg == 0) {
+                    // upper bounds of the UNPERTURBED scores: low bits all ones for a positive value, all zeros for a negative one
+                    const uint32_t b1 = __float_as_uint(x1), b2 = __float_as_uint(x2), b3 = __float_as_uint(x3);
+                    const uint32_t f1 = (b1 & 0xffffffc0u) + ((int32_t)b1 >= 0 ? 64u : 0u);   // = rq_up26 of that bound
+                    const uint32_t u2 = (int32_t)b2 >= 0 ? (b2 | 63u) : (b2 & 0xffffffc0u);
+                    const uint32_t u3 = (int32_t)b3 >= 0 ? (b3 | 63u) : (b3 & 0xffffffc0u);
+                    const uint32_t c2 = rq_code16(__uint_as_float(u2)), c3 = rq_code16(__uint_as_float(u3)), d = c2 - c3;   // c3 <= c2
+                    stg[(16 * (QG * wave + g) + r16) * SQ + (lq & (SQ - 1))] =
+                        make_uint2(f1 | (b1 & 63u), (c2 << 16) | ((d < 1023u ? d : 1023u) << 6) | (b2 & 63u));
+                }
+            }
+        } else
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+            // merge the four lane groups that share this query (lanes r16, r16+16, r16+32, r16+48): all end up equal
+            float x1 = m1[g], x2 = m2[g], x3 = m3[g];
+            uint32_t xp = (ap[g] & 0xffffu) + (uint32_t)(4 * kg) * 0x0101u;
+#pragma unroll
+            for (int off = 16; off <= 32; off <<= 1) {
+                const float o1 = __shfl_xor(x1, off, 64), o2 = __shfl_xor(x2, off, 64), o3 = __shfl_xor(x3, off, 64);
+                const uint32_t op = (uint32_t)__shfl_xor((int)xp, off, 64);
+                const bool ow = o1 > x1 || (o1 == x1 && (op & 0xffu) < (xp & 0xffu));
+                const float w1 = ow ? o1 : x1, w2 = ow ? o2 : x2, w3 = ow ? o3 : x3;
+                const float l1 = ow ? x1 : o1, l2 = ow ? x2 : o2;
+                const uint32_t wp = ow ? op : xp, lp = ow ? xp : op;
+                const bool tl = l1 > w2 || (l1 == w2 && (lp & 0xffu) < (wp >> 8));
+                x1 = w1;
+                x2 = tl ? l1 : w2;
+                x3 = tl ? fmaxf(w2, l2) : fmaxf(w3, l1);
+                xp = (wp & 0xffu) | (tl ? (lp & 0xffu) << 8 : (wp & 0xff00u));
+            }
+            wmax[g] = fmaxf(wmax[g], x1);
+            if (kg == 0) {
+                const uint32_t c2 = rq_code16(x2), c3 = rq_code16(x3), d = c2 - c3;
+                stg[(16 * (QG * wave + g) + r16) * SQ + (lq & (SQ - 1))] =
+                    make_uint2(rq_up26(x1) | (xp & 63u), (c2 << 16) | ((d < 1023u ? d : 1023u) << 6) | ((xp >> 8) & 63u));
+            }
+        }
+        if ((lq & (SQ - 1)) == SQ - 1 || lq == nloc - 1)
+            flush(q_lo + (lq & ~(SQ - 1)), (lq & (SQ - 1)) + 1);
+    }
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        const int ql = 16 * (QG * wave + g) + r16;
+        if (kg == 0 && ql < a.nq_valid) a.wgmax[(int64_t)ql * a.wgmax_stride + b] = wmax[g];
+    }
+}
+
+static constexpr size_t rq_scanw_lds_bytes(int QW, int QG) { return (size_t)4 * 24576 + 512 + (size_t)16 * QW * QG * rqw_sq(QW, QG) * 8; }
+
+template <bool NT, int D, int OCC, int QW, int QG, int EPI, int DBG>
+__global__ __launch_bounds__(64 * QW, OCC) void rq_scanw_kernel(RqScanArgs a) {
+    rq_scanw_body<NT, D, QW, QG, EPI, DBG>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+template <bool NT, int D, int OCC, int QW, int QG, int EPI = 0, int DBG = 0>
+static hipError_t rq_scanw_launch_t(const RqScanArgs& a, int grid, hipStream_t stream) {
+    constexpr size_t lds = rq_scanw_lds_bytes(QW, QG);
+    static_assert(lds <= 160 * 1024, "LDS of one workgroup");
+    static unsigned long long attr_done = 0;   // one bit per device
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (!((attr_done >> (dev & 63)) & 1ull)) {
+        e = hipFuncSetAttribute((const void*)rq_scanw_kernel<NT, D, OCC, QW, QG, EPI, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done |= 1ull << (dev & 63);
+    }
+    hipLaunchKernelGGL((rq_scanw_kernel<NT, D, OCC, QW, QG, EPI, DBG>), dim3(grid), dim3(64 * QW), lds, stream, a);
+    return hipGetLastError();
+}
+
+// Variants (option "wide128" / "wide256"; queries per pass = 16 * waves * groups):
+//   0  128 queries: 8 waves x 1 group, reads 12 fragments ahead                    <- default for 128
+//   1  128 queries: 8 waves x 1 group, reads 4 ahead
+//   2  256 queries: 8 waves x 2 groups, reads 2 ahead (256 VGPRs, nothing spilled in the loop)  <- default for 256
+//   3  256 queries: 8 waves x 2 groups, reads 3 ahead
+//   4  128 queries: as 1 with rq_scan.hip's compare/select epilogue (A/B of the selection forms)
+//   5  128 queries: 4 waves x 2 groups, one wave per SIMD (A/B: a lone wave cannot overlap its own VALU with its MFMAs)
+//   90..92  timing experiments on variant 4's shape, results invalid: no epilogue / no LDS reads / no MFMAs
+hipError_t rq_scan_wide_launch(const RqScanArgs& a, int variant, int queries, bool nt, int grid, hipStream_t stream) {
+    if (grid <= 0) return hipErrorInvalidValue;
+#define RQW_CASE(V, DD, OO, QQ, GG, ...) \
+    if (variant == V && queries == 16 * QQ * GG) \
+        return nt ? rq_scanw_launch_t<true, DD, OO, QQ, GG, ##__VA_ARGS__>(a, grid, stream) : rq_scanw_launch_t<false, DD, OO, QQ, GG, ##__VA_ARGS__>(a, grid, stream);
+    RQW_CASE(0, 12, 2, 8, 1, 1) RQW_CASE(1, 4, 2, 8, 1, 1) RQW_CASE(2, 2, 2, 8, 2, 1) RQW_CASE(3, 3, 2, 8, 2, 1)
+    RQW_CASE(4, 4, 2, 8, 1, 0) RQW_CASE(5, 4, 1, 4, 2, 1)
+    RQW_CASE(90, 4, 2, 8, 1, 0, 1) RQW_CASE(91, 4, 2, 8, 1, 0, 2) RQW_CASE(92, 4, 2, 8, 1, 0, 3)
+#undef RQW_CASE
+    return hipErrorInvalidValue;
+}

@@ -7,6 +7,7 @@
 // order = (fp32 score desc, row asc).
 #include "rq_device.h"
 #include "rq_kernels.h"
+#include "rq_final_body.h"   // RQ_TINY_QUERY_NORM
 
 // --------------------------------------------------------------------------------------------
 // small helpers
@@ -14,36 +15,62 @@
 // rq_wave_sum / rq_sanitize / rq_wave_max_u64: rq_device.h
 
 // --------------------------------------------------------------------------------------------
-// row norms: one wave per row, lane l owns elements p*256 + 4*l + e (p < 3, e < 4)
+// row norms: one wave per row, lane l owns elements p*256 + 4*l + e (p < 3, e < 4).
+// The matrix cores flush fp16 SUBNORMAL inputs to zero (measured: tests/test_gpu_parity.py, subnormal rows score 0 in the
+// scan), so the scan's score of a row misses the products of its subnormal elements: at most
+// sqrt(sum of their squares) * |q| by Cauchy-Schwarz.  stats[1] / stats[2] keep the shard's largest such mass relative to
+// the row norm (cosine) and absolute (inner product); rq_api.hip adds them to the certificate's error bound.
+// stats[0] = largest row norm.  (Bits of non-negative doubles order as integers.)
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rq_rownorm_kernel(const char* x, int64_t row_begin, int64_t row_end, double* norm64) {
+__global__ __launch_bounds__(256) void rq_rownorm_kernel(const char* x, int64_t row_begin, int64_t row_end, double* norm64,
+                                                         unsigned long long* stats) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
+    double mx_norm = 0.0, mx_rel = 0.0, mx_abs = 0.0;
     for (int64_t row = row_begin + wave; row < row_end; row += nwaves) {
         const char* r = x + row * (RQ_DPAD * 2);
-        double acc = 0.0;
+        double acc = 0.0, sub = 0.0;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const rq_half4 v = *(const rq_half4*)(r + p * 512 + lane * 8);
+            const ushort4 b = *(const ushort4*)(r + p * 512 + lane * 8);
+            const unsigned short bits[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const double d = (double)(float)v[e]; acc += d * d; }
+            for (int e = 0; e < 4; ++e) {
+                const double d = (double)(float)v[e];
+                acc += d * d;
+                if ((bits[e] & 0x7c00u) == 0) sub += d * d;   // exponent field 0: zero or subnormal
+            }
         }
         acc = rq_wave_sum(acc);
-        if (lane == 0) norm64[row] = sqrt(acc);
+        sub = rq_wave_sum(sub);
+        const double nrm = sqrt(acc);
+        if (lane == 0) norm64[row] = nrm;
+        if (nrm == nrm && nrm <= 1.7e308) {   // (rows with non-finite elements never certify anyway)
+            mx_norm = fmax(mx_norm, nrm);
+            if (sub > 0.0) { mx_abs = fmax(mx_abs, sqrt(sub)); mx_rel = fmax(mx_rel, sqrt(sub / acc)); }
+        }
+    }
+    if (lane == 0) {
+        atomicMax(&stats[0], (unsigned long long)__double_as_longlong(mx_norm));
+        if (mx_rel > 0.0) atomicMax(&stats[1], (unsigned long long)__double_as_longlong(mx_rel));
+        if (mx_abs > 0.0) atomicMax(&stats[2], (unsigned long long)__double_as_longlong(mx_abs));
     }
 }
-hipError_t rq_rownorm_launch(const void* x, int64_t row_begin, int64_t row_end, double* norm64, hipStream_t stream) {
+hipError_t rq_rownorm_launch(const void* x, int64_t row_begin, int64_t row_end, double* norm64, unsigned long long* stats, hipStream_t stream) {
     if (row_end <= row_begin) return hipSuccess;
     int64_t rows = row_end - row_begin;
     int grid = (int)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);
-    hipLaunchKernelGGL(rq_rownorm_kernel, dim3(grid), dim3(256), 0, stream, (const char*)x, row_begin, row_end, norm64);
+    hipLaunchKernelGGL(rq_rownorm_kernel, dim3(grid), dim3(256), 0, stream, (const char*)x, row_begin, row_end, norm64, stats);
     return hipGetLastError();
 }
 
+// The scan multiplies its accumulator by row_scale.  Queries reach the matrix cores as fp16(q/|q| * 2^12) (see
+// rq_prep_queries_kernel), so both scale arrays carry the factor 2^-12: exact powers of two, the product is unchanged.
 __global__ void rq_rowscale_kernel(const double* norm64, int64_t row_begin, int64_t row_end, float* inv_norm) {
     const int64_t i = row_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < row_end) { const double n = norm64[i]; inv_norm[i] = n > 0.0 ? (float)(1.0 / n) : 0.f; }
+    if (i < row_end) { const double n = norm64[i]; inv_norm[i] = n > 0.0 ? (float)(1.0 / n) * RQ_QSCALE_INV : 0.f; }
 }
 hipError_t rq_rowscale_launch(const double* norm64, int64_t row_begin, int64_t row_end, float* inv_norm, hipStream_t stream) {
     if (row_end <= row_begin) return hipSuccess;
@@ -120,6 +147,8 @@ hipError_t rq_pad_f16_launch(const void* src, int dim, int64_t n, void* dst, hip
 
 // --------------------------------------------------------------------------------------------
 // query preparation: one wave-sized pass per query (block = 256 threads, thread t owns 3 elements)
+// qh = fp16(q / |q| * 2^12): |element| <= 4096, and an element is flushed by the matrix cores (fp16 subnormal) only below
+// 2^-26 of the unit query -- at most sqrt(768) * 2^-26 = 4e-7 of score error, against 1.7e-3 without the scaling.
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rq_prep_queries_kernel(const float* q, int dim, int B, _Float16* qh, float* q32pad, double* qnorm64) {
     __shared__ double part[4];
@@ -140,7 +169,7 @@ __global__ __launch_bounds__(256) void rq_prep_queries_kernel(const float* q, in
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
         const int i = p * 256 + tid;
-        const float f = nrm > 0.0 ? (float)((double)v[p] / nrm) : 0.f;
+        const float f = nrm > 0.0 ? (float)((double)v[p] / nrm) * RQ_QSCALE : 0.f;
         qh[(size_t)qi * RQ_DPAD + i] = (_Float16)f;
         q32pad[(size_t)qi * RQ_DPAD + i] = v[p];
     }
@@ -305,8 +334,8 @@ __global__ __launch_bounds__(RQ_SEL_THREADS) void rq_final_kernel(RqFinalArgs a)
         const int64_t kk = a.k < a.n_rows ? a.k : a.n_rows;   // rows that must be returned
         if (a.nbins <= a.nb) {
             ok = 1;   // the whole shard was re-scored
-        } else if (have < kk) {
-            ok = 0;
+        } else if (have < kk || (a.metric == 0 && a.qnorm64[q] != 0.0 && a.qnorm64[q] < RQ_TINY_QUERY_NORM)) {
+            ok = 0;   // (tiny query: see rq_final_body.h RQ_TINY_QUERY_NORM)
         } else if (kk == 0) {
             ok = 1;
         } else {

@@ -175,6 +175,30 @@ def test_every_kernel_variant_is_exact(corpus100k, opts):
     idx.close()
 
 
+@pytest.mark.parametrize("opts", [dict(wide_batch=1), dict(wide_batch=3), dict(wide_batch=2), dict(wide_batch=0),
+                                  # every variant built in csrc/rq_scan_wide.hip: 128-query passes 0 / 1 / 4 / 5, 256-query passes 2 / 3
+                                  dict(wide_batch=3, wide128=1), dict(wide_batch=3, wide128=4), dict(wide_batch=3, wide128=5),
+                                  dict(wide_batch=1, wide256=3), dict(wide_batch=1, nt=1), dict(wide_batch=1, cu_count=5)])
+def test_every_wide_pass_variant_is_exact(corpus100k, opts):
+    """Calls with more than 64 queries are cut into passes of 256 / 128 / 64 queries (csrc/rq_api.hip run_pipeline).
+    B = 333 -> 256 + 128 (77 valid); B = 100 -> 128; B = 200 -> 256; ragged shard (30 011 rows), duplicates, a zero query."""
+    _, x16 = corpus100k
+    x = x16[:30_011].copy()
+    x[200:260] = x[7]
+    idx = nat.NativeIndex(768, 0)
+    idx.add_f16(x)
+    for name, v in opts.items():
+        idx.set_option(name, v)
+    for B, k in ((333, 10), (100, 50), (200, 100)):
+        q = orc.synthetic_queries(B, 768, seed=B)
+        q[1] = 0
+        q[2] = x[7].astype(np.float32)
+        _check(idx, x, q, k)
+    _check(idx, x, 2.5 * orc.synthetic_queries(130, 768, seed=3), 10, nat.METRIC_IP)
+    assert idx.timing()["exact_scans"] == 0
+    idx.close()
+
+
 @pytest.mark.parametrize("mode", [1, 2])
 def test_deferred_tails_over_many_batches(mode):
     """pipeline = 1 (internal tail stream) and 2 (the tail of batch i rides in the scan launch of batch i+1):
@@ -471,6 +495,41 @@ def test_fused_headline_instantiation_matches_oracle(n, expect_nv):
     idx.close()
 
 
+def test_wide_batches_at_headline_size_match_oracle():
+    """BASELINE.json configs[3] / [4] batch shapes on the 1M x 768 corpus: 256 queries (one 256-query pass), 128 queries
+    (one 128-query pass) and 500 queries top-100 (256 + 256 with 244 valid) through the blocking host API and the device
+    API -- rows identical to the oracle, |score difference| <= 1e-6, nothing repaired."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 1_000_000
+    idx = nat.NativeIndex(768, 0)
+    _device_corpus(idx, n, 1235)
+    q128 = orc.synthetic_queries(128, 768, seed=51)
+    q256 = orc.synthetic_queries(256, 768, seed=52)
+    q500 = orc.synthetic_queries(500, 768, seed=53)
+    q256[:3] = np.stack([idx.get_rows_f16(p, 1)[0] for p in (7, 500_000, n - 1)]).astype(np.float32)
+    s128, r128 = idx.search(q128, 10)
+    s500, r500 = idx.search(q500, 100)
+    dq = torch.from_numpy(q256).to(dev)
+    sc = torch.empty((256, 10), device=dev); rw = torch.empty((256, 10), device=dev, dtype=torch.int64); st = torch.full((256,), 9, device=dev, dtype=torch.int32)
+    idx.search_device(dq, 256, 10, 0, sc, rw, None, st, 0)
+    torch.cuda.synchronize()
+    assert int(st.abs().sum()) == 0
+    t = idx.timing()
+    assert t["widened"] == 0 and t["exact_scans"] == 0
+    x16 = idx.get_rows_f16(0, n)
+    sub500 = np.arange(0, 500, 4)                                             # every 4th of the 500 (the oracle pass is the slow part)
+    exact = orc.exact_scores(np.concatenate([q128, q256, q500[sub500]], 0), x16)
+    es, er = orc.topk_from_scores(exact[:128], 10)
+    assert np.array_equal(r128, er) and float(np.abs(s128 - es).max()) <= SCORE_TOL
+    es, er = orc.topk_from_scores(exact[128:384], 10)
+    assert np.array_equal(rw.cpu().numpy(), er) and float(np.abs(sc.cpu().numpy() - es).max()) <= SCORE_TOL
+    assert er[:3, 0].tolist() == [7, 500_000, n - 1]
+    es, er = orc.topk_from_scores(exact[384:], 100)
+    assert np.array_equal(r500[sub500], er) and float(np.abs(s500[sub500] - es).max()) <= SCORE_TOL
+    idx.close()
+
+
 def test_nomic_bert_embedder_end_to_end_random_init():
     """BASELINE.json configs[3] shape: raw text -> PyTorch-ROCm NomicBert forward -> HIP search.  No weights are
     available offline, so the architecture runs with random weights (2 layers to keep the test quick) and a
@@ -754,14 +813,15 @@ def test_multi_device_index_in_one_process():
         assert one.search(text, 25) == many.search(text, 25)
 
 
-@pytest.mark.parametrize("n", [40_000, 40_033, 4_101])
-def test_scan_bin_maxima_within_certificate_eps(n):
+@pytest.mark.parametrize("n,B", [(40_000, 64), (40_033, 64), (4_101, 64), (40_033, 128), (40_000, 256), (4_101, 256)])
+def test_scan_bin_maxima_within_certificate_eps(n, B):
     """The certificate assumes |approximate scan score - exact score| <= eps = 7e-4.  Read the
     scan's per-bin maxima back (bin = quad of 64 consecutive rows) and compare them with the exact per-bin maxima
     from the oracle: validates the MFMA fragment layout, the LDS swizzle, the cross-lane merge, the contiguous
-    quad ranges of the workgroups (ragged 4-quad store groups at their edges) and the bound itself."""
+    quad ranges of the workgroups (ragged 4-quad store groups at their edges) and the bound itself.  B = 128 / 256 run
+    the wide passes of csrc/rq_scan_wide.hip (read-ahead stream across stage barriers, v_med3 selection with the row
+    position in the low mantissa bits, NaN row scales for the pad rows)."""
     import torch
-    B = 64
     x16 = orc.synthetic_corpus(n, 768, seed=61)
     x16[5] = 0
     q = orc.synthetic_queries(B, 768, seed=62) * 17.0
@@ -781,7 +841,7 @@ def test_scan_bin_maxima_within_certificate_eps(n):
         idx.search_device(dq, B, 10, 0, sc, rw, None, st, 0)
         torch.cuda.synchronize()
         worst = 0.0
-        for qi in (0, 3, 17, 63):
+        for qi in (0, 3, 17, 63, B - 1, B // 2 + 5):
             pooled = idx.debug_pooled(qi, nbins)
             assert pooled.shape == (nbins,)
             e = np.where(valid, exact[qi][np.minimum(rows, n - 1)], -np.inf).max(axis=1)
@@ -789,6 +849,75 @@ def test_scan_bin_maxima_within_certificate_eps(n):
             worst = max(worst, float(np.abs(pooled - e).max()))
         assert worst <= 7e-4, worst
         assert worst <= 1e-4, f"observed error {worst} is far above the ~1e-5 expected from fp16 query rounding"
+    idx.close()
+
+
+def _pooled_error(idx, x16, q, queries):
+    import torch
+    dev = torch.device("cuda:0")
+    B, n = q.shape[0], x16.shape[0]
+    dq = torch.from_numpy(q).to(dev)
+    sc = torch.empty((B, 10), device=dev); rw = torch.empty((B, 10), device=dev, dtype=torch.int64); st = torch.empty((B,), device=dev, dtype=torch.int32)
+    idx.search_device(dq, B, 10, 0, sc, rw, None, st, 0)
+    torch.cuda.synchronize()
+    exact = orc.exact_scores(q, x16)
+    nbins = (n + 63) // 64
+    rows = np.arange(nbins)[:, None] * 64 + np.arange(64)[None, :]
+    worst = 0.0
+    for qi in queries:
+        pooled = idx.debug_pooled(qi, nbins)
+        e = np.where(rows < n, exact[qi][np.minimum(rows, n - 1)], -np.inf).max(axis=1)
+        worst = max(worst, float(np.abs(pooled - e).max()))
+    return worst
+
+
+@pytest.mark.parametrize("B", [64, 128])
+def test_fp16_subnormals_are_covered_by_the_error_bound(B):
+    """The matrix cores flush fp16 SUBNORMAL operands to zero (this test found it: an all-subnormal corpus scores 0 in the
+    scan).  What the bound eps = 7e-4 of the certificate rests on instead (csrc/rq_select.hip, csrc/rq_api.hip scan_eps):
+      * queries reach the matrix cores as fp16(q/|q| * 2^12), so a query element is flushed only below 2^-26 of the unit
+        query: a query whose unit image is 4 ordinary + 764 tiny elements must keep its bin maxima within eps;
+      * the share of a stored row's norm that sits in subnormal elements is measured at add time; its shard maximum is
+        ADDED to eps (ordinary unit rows: ~1e-4), and a shard where it is hopeless is scanned exactly."""
+    rng = np.random.default_rng(99)
+    n = 20_000
+    # (1) ordinary corpus, subnormal-heavy queries
+    x16 = orc.synthetic_corpus(n, 768, seed=3)
+    q = rng.standard_normal((B, 768)).astype(np.float32) * 1e-6
+    q[:, :4] = rng.standard_normal((B, 4)).astype(np.float32)                 # unit image: 4 ordinary elements, 764 below 6.1e-5
+    q[5] = rng.standard_normal(768).astype(np.float32) * 1e-10                # a small query
+    q[6] = rng.standard_normal(768).astype(np.float32) * 1e-30                # so small that the 1e-30 of the score definition shows:
+    idx = nat.NativeIndex(768, 0)                                             #   never certified from the scan, exact route (rq_final_body.h)
+    idx.add_f16(x16)
+    rel = idx.get_option("max_sub_rel")
+    assert 0.0 < rel < 5e-4, rel                                              # a Gaussian unit row has ~1 subnormal element
+    assert idx.get_option("eps_cosine") == pytest.approx(7e-4 + rel, rel=1e-3)
+    _check(idx, x16, q, 10)
+    assert idx.timing()["exact_scans"] == 1                                   # query 6 only
+    assert _pooled_error(idx, x16, q, (0, 5, 9, B - 1)) <= 7e-4 + rel
+    idx.close()
+    # (2) rows made of subnormal elements only (cosine rescales them by 1/norm ~ 1e3): the scan sees zeros, the bound says so,
+    #     the search goes through the exact route and stays exact
+    x16 = (rng.standard_normal((n, 768)) * 2e-5).astype(np.float16)
+    assert (np.abs(x16.astype(np.float32)) < 6.2e-5).mean() > 0.99 and (x16 != 0).mean() > 0.9
+    x16[100:120] = orc.synthetic_corpus(20, 768, seed=3)                       # a few ordinary rows among them
+    idx = nat.NativeIndex(768, 0)
+    idx.add_f16(x16)
+    assert idx.get_option("max_sub_rel") > 0.9 and idx.get_option("eps_cosine") > 0.9
+    _check(idx, x16, orc.synthetic_queries(B, 768, seed=4), 10)
+    _check(idx, x16, 3.0 * orc.synthetic_queries(7, 768, seed=5), 10, nat.METRIC_IP)
+    idx.close()
+    # (3) unit rows with a planted block of subnormal elements (a tenth of the norm hidden from the scan): bound grows, search exact
+    x32 = rng.standard_normal((n, 768)).astype(np.float32)
+    x32[:, 300:] *= 2e-4                                                      # 468 elements of ~2e-4 / 0.06 = below the fp16 normal range after normalisation
+    x16 = orc.prepare_rows_f32(x32, True)
+    idx = nat.NativeIndex(768, 0)
+    idx.add_f16(x16)
+    rel = idx.get_option("max_sub_rel")
+    assert 1e-4 < rel < 0.05, rel
+    _check(idx, x16, q, 10)
+    assert _pooled_error(idx, x16, q, (0, 9, B - 1)) <= 7e-4 + rel
+    assert idx.timing()["exact_scans"] == 1                                   # the tiny query 6 again, nothing else
     idx.close()
 
 
