@@ -47,7 +47,21 @@ def main() -> None:
     ap.add_argument("--streams", type=int, default=0, help="caller streams the batches alternate over (0 = 1 at one GPU, 2 at several)")
     ap.add_argument("--event-stride", type=int, default=4, help="HIP events around every n-th scan launch of the timed region")
     ap.add_argument("--pipeline", type=int, default=2, help="deferred tails: 1 = on the library's internal stream, 2 = fused into the next scan launch")
+    ap.add_argument("--workload", default="headline", choices=["headline", "config2", "config3", "config4"],
+                    help="headline = BASELINE.json configs[1] (the metric); config2/3/4 = the other GPU configs at their shapes on ONE GPU "
+                         "(tools/config_workloads.py, synthetic stand-ins), one JSON line each")
     args = ap.parse_args()
+    if args.workload != "headline":
+        if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
+            raise SystemExit("--workload config2/3/4 are single-GPU legs")
+        from tools import config_workloads as cw
+        r = {"config2": cw.run_config2, "config3": cw.run_config3, "config4": cw.run_config4}[args.workload]()
+        metric = {"config2": ("queries/sec, 10M x 768 fp16 in 8 row shards on one GPU, batch-64, top-10", r.get("queries_per_s")),
+                  "config3": ("text queries/sec end to end (NomicBert forward + search over 1M x 768), 256 per call", r.get("text_queries_per_s")),
+                  "config4": ("questions/sec, GPU dense top-100 + CPU BM25 top-100 + fusion, 500 per call", r.get("questions_per_s_hybrid"))}[args.workload]
+        print(json.dumps({"metric": metric[0], "value": metric[1], "unit": "queries/s", "n_gpus": 1, "higher_is_better": True,
+                          "vs_baseline": None, "dtype": "f16", "data": r["data"], "config": {"workload": r["workload"]}, "details": r}), flush=True)
+        return
 
     import numpy as np
     import torch
@@ -155,11 +169,25 @@ def main() -> None:
             if pending["n"] == GATHER_EVERY:
                 flush()
 
+    status_host = torch.zeros((N_QUERY_BATCHES, B), dtype=torch.int32).pin_memory()
+
+    def finish():
+        """End of a timed run: the certificate status of every slot rides home in stream order (one 4 KB copy into pinned
+        memory behind the last tail) and ONE synchronisation follows -- instead of synchronise, blocking copy, synchronise,
+        whose host latencies (~300 us in all, kernel timeline in profiles/r02_trace20_gaps.txt) a 20-step run cannot amortise."""
+        last = comm_stream if use_comm else streams[0]
+        for s in streams:
+            if s is not last:
+                last.wait_stream(s)
+        with torch.cuda.stream(last):
+            status_host.copy_(status_all, non_blocking=True)
+        torch.cuda.synchronize()
+
     def fixup_all() -> int:
         """certificate check of every slot (inside the timed region): repairs uncertified queries exactly"""
         fixed = 0
         nslots = min(N_QUERY_BATCHES, args.steps)
-        bad = status_all[:nslots].cpu().numpy().any(axis=1)           # one 4 KB copy (the callers have flushed and synchronised)
+        bad = status_host[:nslots].numpy().any(axis=1)                # (finish() has copied and synchronised)
         for j in np.nonzero(bad)[0].tolist():
             o = slots[j]
             fixed += idx.search_fixup_device(queries[j], B, k, nat.METRIC_COSINE, o["scores"], o["rows"], o["keys"], o["status"], 0)
@@ -214,7 +242,7 @@ def main() -> None:
     for i in range(args.steps):
         step(i)
     flush()
-    torch.cuda.synchronize()
+    finish()
     fixed = fixup_all()
     sync_all()
     elapsed = time.perf_counter() - t0

@@ -36,6 +36,32 @@ class HashEmbedder:
         return out
 
 
+class RandomProjectionEmbedder:
+    """Deterministic offline stand-in for a text encoder: every lower-cased whitespace token owns a fixed Gaussian
+    direction (seeded by SHA-256 of the token), a text is the sum of its tokens' directions.  Cosine similarity then
+    follows token overlap, which is what synthetic retrieval workloads need when no model weights are available
+    (BASELINE.json configs[4] stand-in; HashEmbedder has no such structure).  Not a language model."""
+
+    def __init__(self, dim: int = 768):
+        self.dim = int(dim)
+        self._cache = {}
+
+    def _token(self, tok: str) -> np.ndarray:
+        v = self._cache.get(tok)
+        if v is None:
+            seed = int.from_bytes(hashlib.sha256(tok.encode()).digest()[:8], "little")
+            v = np.random.default_rng(seed).standard_normal(self.dim).astype(np.float32)
+            self._cache[tok] = v
+        return v
+
+    def embed(self, texts: Sequence[str]) -> np.ndarray:
+        out = np.zeros((len(texts), self.dim), dtype=np.float32)
+        for i, t in enumerate(texts):
+            for tok in t.lower().split():
+                out[i] += self._token(tok)
+        return out
+
+
 class CallableEmbedder:
     """Wrap any `fn(list_of_texts) -> array[n, dim]` (e.g. a client of an embedding service)."""
 

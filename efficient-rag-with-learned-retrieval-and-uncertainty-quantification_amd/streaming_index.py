@@ -520,11 +520,15 @@ class HybridRetriever:
             texts += [""] * pad
         return bm25_scores, dense_scores, doc_ids, texts
 
-    def get_scores_for_router(self, query: str, num_passages: int = 20) -> Tuple[List[float], List[float], List[str], List[str]]:
-        return self._router_arrays(self.hybrid_search(query, top_k=num_passages), num_passages)
+    def get_scores_for_router(self, query: str, num_passages: int = 20, *, retrieval_pool_size: int = 50
+                              ) -> Tuple[List[float], List[float], List[str], List[str]]:
+        """Reference :525-557 (its pools are always 50, :537); `retrieval_pool_size` is a keyword-only extension for
+        BASELINE.json configs[4] (top-100 pools)."""
+        return self._router_arrays(self.hybrid_search(query, top_k=num_passages, retrieval_pool_size=retrieval_pool_size), num_passages)
 
-    def get_scores_for_router_batch(self, queries: Sequence[str], num_passages: int = 20):
-        return [self._router_arrays(r, num_passages) for r in self.hybrid_search_batch(queries, top_k=num_passages)]
+    def get_scores_for_router_batch(self, queries: Sequence[str], num_passages: int = 20, *, retrieval_pool_size: int = 50):
+        return [self._router_arrays(r, num_passages)
+                for r in self.hybrid_search_batch(queries, top_k=num_passages, retrieval_pool_size=retrieval_pool_size)]
 
     def __len__(self) -> int:
         return len(self.documents)

@@ -9,6 +9,10 @@ What is captured (inputs + the reference's outputs, nothing of its source):
   g3_retrieval_metrics.json  rag_uq.eval_protocol.RAGEvaluator._recall_at_k / _reciprocal_rank / _ndcg_at_k
   g5_hash_embedding.json  rag_uq.streaming_index.DenseIndex._get_embedding fallback (:269-273), HAS_OLLAMA False
   g6_records.json         Document.to_dict / from_dict (:62-77)
+  g2_router.json          rag_uq.router.RetrievalRouter(RouterConfig()) with torch.manual_seed(0), .eval(): its state dict and
+                          forward(update_stats=False) / hybrid_rerank outputs on fixed [4,20] / [1,10] / [1,100] score tensors
+                          (router.py:44-202), with batch-wise and with running-statistics normalisation -- pins the
+                          consumer of the hot path that BASELINE.json configs[4] feeds
   g4_oracle_dense.json    the oracle's own answers on seeded inputs (regression pin of oracle/dense_oracle.py;
                           NOT a reference output: the reference's dense arithmetic lives in ChromaDB, absent here)
 """
@@ -120,6 +124,37 @@ def run_records():
     return dict(to_dict=[d1.to_dict(), d2.to_dict()], from_dict_minimal=dict(id=rt.id, text=rt.text, title=rt.title, metadata=rt.metadata))
 
 
+def run_router():
+    import torch
+    from rag_uq.router import RetrievalRouter, RouterConfig
+    torch.manual_seed(0)
+    router = RetrievalRouter(RouterConfig()).eval()
+    state = {k: v.detach().cpu().numpy().tolist() for k, v in router.state_dict().items()}
+    g = torch.Generator().manual_seed(1)
+    cases = []
+    for shape, scale, k in (((4, 20), 1.0, 10), ((1, 10), 1.0, 10), ((1, 100), 1.0, 10), ((2, 100), 8.0, 100), ((1, 10), 1.0, 3)):
+        bm25 = (torch.rand(shape, generator=g) * 12.0 * scale).float()
+        dense = (torch.rand(shape, generator=g) * 0.6 + 0.2).float()
+        if shape == (1, 10):
+            bm25[0, 7:] = 0.0; dense[0, 8:] = 0.0           # the zero padding get_scores_for_router appends (:539-557)
+        for stats in (False, True):
+            router.stats_initialized = stats
+            if stats:
+                router.bm25_mean.fill_(3.5); router.bm25_std.fill_(2.25); router.dense_mean.fill_(0.45); router.dense_std.fill_(0.125)
+            with torch.no_grad():
+                w = router(bm25, dense, update_stats=False)
+                top_s, top_i = router.hybrid_rerank(bm25, dense, top_k=k)
+                # the evaluation loop's own rerank (experiments/run_evaluation.py:170-184)
+                hyb = w * dense + (1 - w) * bm25
+                order = [torch.argsort(hyb[b], descending=True).tolist() for b in range(shape[0])]
+            cases.append(dict(shape=list(shape), top_k=k, stats_initialized=stats,
+                              stats=dict(bm25_mean=float(router.bm25_mean), bm25_std=float(router.bm25_std),
+                                         dense_mean=float(router.dense_mean), dense_std=float(router.dense_std)),
+                              bm25=bm25.tolist(), dense=dense.tolist(), weights=w.tolist(),
+                              rerank_scores=top_s.tolist(), rerank_indices=top_i.tolist(), eval_loop_order=order))
+    return dict(config=dict(hidden_dim=64, dropout=0.1, num_layers=2, use_batch_norm=False), state_dict=state, cases=cases)
+
+
 def run_oracle_pin():
     from oracle import dense_oracle as orc
     out = []
@@ -134,6 +169,7 @@ def run_oracle_pin():
 def main():
     dumps = {
         "g1_hybrid_fusion.json": run_fusion(),
+        "g2_router.json": run_router(),
         "g3_retrieval_metrics.json": run_metrics(),
         "g5_hash_embedding.json": run_hash_embedding(),
         "g6_records.json": run_records(),

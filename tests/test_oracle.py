@@ -98,3 +98,32 @@ def test_bm25_oracle_basics():
     assert bm25_oracle.bm25_search(ids, texts, "zebra", 10) == []
     # "the" and "sat" are in 2 of 4 too; "down" only in b
     assert [d for d, _ in bm25_oracle.bm25_search(ids, texts, "the dog sat down", 10)] == ["b"]
+
+
+def test_router_restatement_matches_reference_g2(golden_dir):
+    """oracle/router_oracle.py against the reference's RetrievalRouter (rag_uq/router.py:44-202) as captured in
+    g2_router.json: gating weights, hybrid_rerank and the evaluation loop's order, with batch-wise and with
+    running-statistics normalisation."""
+    from oracle import router_oracle as ro
+    g2 = json.load(open(os.path.join(golden_dir, "g2_router.json")))
+    assert g2["config"] == dict(hidden_dim=64, dropout=0.1, num_layers=2, use_batch_norm=False)
+    for c in g2["cases"]:
+        r = ro.RouterOracle(g2["state_dict"])
+        if c["stats_initialized"]:
+            r.set_stats(**c["stats"])
+        w = r.forward(c["bm25"], c["dense"])
+        np.testing.assert_allclose(w, np.asarray(c["weights"], np.float32), rtol=0, atol=2e-6)
+        s, i = r.hybrid_rerank(c["bm25"], c["dense"], c["top_k"])
+        np.testing.assert_allclose(s, np.asarray(c["rerank_scores"], np.float32), rtol=2e-6, atol=2e-6)
+        hyb = r.hybrid_scores(c["bm25"], c["dense"])
+
+        def same_order(mine, ref, b):
+            # identical up to the order INSIDE a group of exactly tied hybrid scores (the zero padding of
+            # get_scores_for_router ties at 0.0; torch.topk / argsort leave that order unspecified)
+            return len(mine) == len(ref) and all(m == t or hyb[b][m] == hyb[b][t] for m, t in zip(mine, ref))
+        for b in range(c["shape"][0]):
+            assert same_order(i[b].tolist(), c["rerank_indices"][b], b)
+            if c["shape"][0] == 1:      # the loop of run_evaluation.py:170-184 normalises one question at a time
+                assert same_order(r.eval_loop_order(c["bm25"][b], c["dense"][b]), c["eval_loop_order"][b], b)
+    for c in json.load(open(os.path.join(golden_dir, "g3_retrieval_metrics.json"))):
+        assert ro.recall_at_k(c["retrieved"], c["relevant"], c["k"]) == pytest.approx(c["recall_at_k"])
