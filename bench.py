@@ -241,11 +241,16 @@ def main() -> None:
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    t_enq = time.perf_counter()
     flush()
     finish()
+    t_fin = time.perf_counter()
     fixed = fixup_all()
-    sync_all()
-    elapsed = time.perf_counter() - t0
+    if use_comm or fixed:
+        sync_all()      # (at one GPU with nothing repaired, finish() ended with torch.cuda.synchronize() and nothing was enqueued since:
+    elapsed = time.perf_counter() - t0   # that synchronisation IS the closing bracket; a second one costs ~100 us of host time on an idle device)
+    host_phases = {"enqueue_all_steps_us": (t_enq - t0) * 1e6, "flush_copy_sync_us": (t_fin - t_enq) * 1e6,
+                   "status_check_and_final_sync_us": (t0 + elapsed - t_fin) * 1e6}
     if use_comm:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -321,6 +326,7 @@ def main() -> None:
                                           "a live interval would start when the launch is dequeued and include the wait for the "
                                           "other stream's scan to release its workgroup slots (queue wait + execution)"}},
         "repaired_queries": fixed,
+        "host_phases": host_phases,
         "exact_scans": timing["exact_scans"],
     }
 

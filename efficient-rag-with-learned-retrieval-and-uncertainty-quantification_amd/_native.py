@@ -10,7 +10,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 from pathlib import Path
-from typing import Optional, Tuple
+from typing import Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -59,6 +59,7 @@ _SIGNATURES = {
     "rq_search_fixup_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "rq_search_flush_device": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rq_stream_release": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rq_merge_keys_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
     "rq_debug_pooled": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
@@ -130,18 +131,21 @@ def _ptr(a) -> C.c_void_p:
 
 
 class NativeIndex:
-    """Thin owner of one rq_index handle (one row shard on one GPU)."""
+    """Thin owner of one rq_index handle: one row shard on one GPU, or -- `devices=[...]` with more than one entry -- rows
+    sharded across several GPUs inside the library (host-buffer calls only, see include/rq.h rq_index_create)."""
 
-    def __init__(self, dim: int, device: int = 0, _handle: Optional[int] = None):
+    def __init__(self, dim: int, device: int = 0, _handle: Optional[int] = None, devices: Optional[Sequence[int]] = None):
         self._lib = load_library()
+        devs = [int(d) for d in devices] if devices else [int(device)]
         if _handle is None:
-            ids = (C.c_int * 1)(int(device))
-            _handle = self._lib.rq_index_create(int(dim), 1, ids)
+            ids = (C.c_int * len(devs))(*devs)
+            _handle = self._lib.rq_index_create(int(dim), len(devs), ids)
             if not _handle:
-                raise RqError(f"rq_index_create(dim={dim}, device={device}): {last_error()}")
+                raise RqError(f"rq_index_create(dim={dim}, devices={devs}): {last_error()}")
         self._h = C.c_void_p(_handle)
         self.dim = int(self._lib.rq_index_dim(self._h))
-        self.device = int(device)
+        self.device = devs[0]
+        self.devices = devs
 
     # -- lifetime ---------------------------------------------------------------------------
     def close(self) -> None:
@@ -216,6 +220,10 @@ class NativeIndex:
     def search_flush_device(self, stream: int = 0) -> None:
         _check(self._lib.rq_search_flush_device(self._h, C.c_void_p(stream)), "rq_search_flush_device")
 
+    def stream_release(self, stream: int = 0) -> None:
+        """Drop the search workspace kept for `stream` (call before destroying a stream that was used for searches)."""
+        _check(self._lib.rq_stream_release(self._h, C.c_void_p(stream)), "rq_stream_release")
+
     def debug_pooled(self, query: int, max_bins: int, stream: int = 0) -> np.ndarray:
         out = np.empty((int(max_bins),), dtype=np.float32)
         n = _check(self._lib.rq_debug_pooled(self._h, C.c_void_p(stream), int(query), _ptr(out), int(max_bins)), "rq_debug_pooled")
@@ -248,13 +256,14 @@ class NativeIndex:
         _check(self._lib.rq_save(self._h, str(path).encode()), "rq_save")
 
     @classmethod
-    def load(cls, path: str, device: int = 0) -> "NativeIndex":
+    def load(cls, path: str, device: int = 0, devices: Optional[Sequence[int]] = None) -> "NativeIndex":
         lib = load_library()
-        ids = (C.c_int * 1)(int(device))
-        h = lib.rq_load(str(path).encode(), 1, ids)
+        devs = [int(d) for d in devices] if devices else [int(device)]
+        ids = (C.c_int * len(devs))(*devs)
+        h = lib.rq_load(str(path).encode(), len(devs), ids)
         if not h:
             raise RqError(f"rq_load({path}): {last_error()}")
-        return cls(0, device, _handle=h)
+        return cls(0, devs[0], _handle=h, devices=devs)
 
 
 def merge_keys_device(d_keys_in, n_per_query: int, B: int, k: int, d_scores, d_rows, d_keys_out=None, stream: int = 0) -> None:

@@ -109,6 +109,13 @@ struct rq_index {
     int h_bcap = 0, h_kcap = 0;
     // small blocking searches (the reference's one-query-per-call pattern): results leave in ONE copy into pinned memory
     char* hs_dev = nullptr; char* hs_pin = nullptr; float* hs_pin_q = nullptr; size_t hs_bytes = 0, hs_qfloats = 0;
+    bool hs_small = false;         // which staging path the search in flight uses (search_begin / search_end)
+    // Multi-device parent (rq_index_create with n_devices > 1): no device memory of its own, one single-device child per
+    // entry of device_ids.  Every appended block is cut into contiguous pieces, piece j goes to child j, so a child holds
+    // several segments of global ids; seg_local[j] = local start of each segment (+ end sentinel), seg_global[j] = its
+    // global start.  Local order inside a child is monotone in the global id.
+    std::vector<rq_index*> shards;
+    std::vector<std::vector<int64_t>> seg_local, seg_global;
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t ev_used = 0;
@@ -140,10 +147,22 @@ static int nb_default(const rq_index* idx, int k) {
 }
 static const int RQ_NB_MAX = 3071;
 
-static int use_device(const rq_index* idx) {
-    HIPCHK(hipSetDevice(idx->device));
-    return RQ_OK;
-}
+// Every entry point works on the index's device and puts the caller's current device back on return (a caller that
+// holds tensors on another GPU, e.g. torch with several devices, must not find its device switched under it).
+struct DeviceGuard {
+    int prev = -1, dev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int d) : dev(d) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define RQ_ON_DEVICE(idx)                                                                                  \
+    DeviceGuard dg_((idx)->device);                                                                        \
+    if (!dg_.ok) return set_err(RQ_EHIP, "cannot select device %d", (idx)->device)
 
 extern "C" int rq_device_count(void) {
     int n = 0;
@@ -154,6 +173,7 @@ extern "C" const char* rq_last_error(void) { return g_err; }
 extern "C" const char* rq_version(void) { return "rq-hip 0.1 (gfx950)"; }
 
 static int flush_all(rq_index* idx);   // launches every tail still waiting for a scan ("pipeline" = 2)
+static const size_t RQ_MAX_STREAM_CTX = 8;
 
 static int grow(rq_index* idx, int64_t want_rows) {
     if (want_rows <= idx->cap) return RQ_OK;
@@ -166,8 +186,11 @@ static int grow(rq_index* idx, int64_t want_rows) {
     char* nx = nullptr; double* nn = nullptr; float* ni = nullptr;
     hipError_t e = hipMalloc((void**)&nx, (size_t)cap * RQ_DPAD * 2);
     if (e != hipSuccess) return set_err(RQ_ENOMEM, "hipMalloc of %lld corpus rows failed: %s", (long long)cap, hipGetErrorString(e));
-    HIPCHK(hipMalloc((void**)&nn, (size_t)cap * sizeof(double)));
-    HIPCHK(hipMalloc((void**)&ni, (size_t)cap * sizeof(float)));
+    if ((e = hipMalloc((void**)&nn, (size_t)cap * sizeof(double))) != hipSuccess || (e = hipMalloc((void**)&ni, (size_t)cap * sizeof(float))) != hipSuccess) {
+        (void)hipFree(nx);
+        if (nn) (void)hipFree(nn);
+        return set_err(RQ_ENOMEM, "hipMalloc of the row statistics of %lld rows failed: %s", (long long)cap, hipGetErrorString(e));
+    }
     const int64_t keep = idx->n;
     if (keep > 0) {
         HIPCHK(hipMemcpyAsync(nx, idx->x, (size_t)keep * RQ_DPAD * 2, hipMemcpyDeviceToDevice, idx->own_stream));
@@ -188,20 +211,21 @@ static int grow(rq_index* idx, int64_t want_rows) {
     return RQ_OK;
 }
 
+static rq_index* multi_create(int dim, int n_devices, const int* device_ids);
+
 extern "C" rq_index* rq_index_create(int dim, int n_devices, const int* device_ids) {
     if (dim < 1 || dim > RQ_MAX_DIM) { set_err(RQ_EINVAL, "dim %d outside 1..%d", dim, RQ_MAX_DIM); return nullptr; }
-    if (n_devices != 1 || !device_ids) {
-        set_err(RQ_EUNSUPPORTED, "n_devices must be 1 (one process per GPU; merge shards with rq_merge_keys_device)");
-        return nullptr;
-    }
+    if (n_devices < 1 || n_devices > 64 || !device_ids) { set_err(RQ_EINVAL, "n_devices %d outside 1..64 or no device list", n_devices); return nullptr; }
+    if (n_devices > 1) return multi_create(dim, n_devices, device_ids);
     const int ndev = rq_device_count();
     if (ndev <= 0) { set_err(RQ_ENODEVICE, "no HIP device visible: the gfx950 backend has no CPU fallback"); return nullptr; }
     if (device_ids[0] < 0 || device_ids[0] >= ndev) { set_err(RQ_EINVAL, "device %d outside 0..%d", device_ids[0], ndev - 1); return nullptr; }
     rq_index* idx = new rq_index();
     idx->dim = dim;
     idx->device = device_ids[0];
+    DeviceGuard dg_(idx->device);
     hipDeviceProp_t prop;
-    if (hipSetDevice(idx->device) != hipSuccess || hipGetDeviceProperties(&prop, idx->device) != hipSuccess) {
+    if (!dg_.ok || hipGetDeviceProperties(&prop, idx->device) != hipSuccess) {
         set_err(RQ_EHIP, "cannot open device %d", idx->device);
         delete idx;
         return nullptr;
@@ -228,19 +252,27 @@ static void free_ws(Workspace& w) {
     w = Workspace();
 }
 
+static void free_ctx(StreamCtx& c) {
+    free_ws(c.w[0]);
+    free_ws(c.w[1]);
+    if (c.tail) (void)hipStreamDestroy(c.tail);
+    for (int p = 0; p < 2; ++p) {
+        if (c.ev_scan[p]) (void)hipEventDestroy(c.ev_scan[p]);
+        if (c.ev_tail[p]) (void)hipEventDestroy(c.ev_tail[p]);
+    }
+    c = StreamCtx();
+}
+
 extern "C" void rq_index_destroy(rq_index* idx) {
     if (!idx) return;
-    (void)hipSetDevice(idx->device);
-    (void)hipDeviceSynchronize();
-    for (auto& kv : idx->ctx) {
-        free_ws(kv.second.w[0]);
-        free_ws(kv.second.w[1]);
-        if (kv.second.tail) (void)hipStreamDestroy(kv.second.tail);
-        for (int p = 0; p < 2; ++p) {
-            if (kv.second.ev_scan[p]) (void)hipEventDestroy(kv.second.ev_scan[p]);
-            if (kv.second.ev_tail[p]) (void)hipEventDestroy(kv.second.ev_tail[p]);
-        }
+    if (!idx->shards.empty()) {
+        for (rq_index* c : idx->shards) rq_index_destroy(c);
+        delete idx;
+        return;
     }
+    DeviceGuard dg_(idx->device);
+    (void)hipDeviceSynchronize();
+    for (auto& kv : idx->ctx) free_ctx(kv.second);
     for (auto& ev : idx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (idx->hs_pin) (void)hipHostFree(idx->hs_pin);
     if (idx->hs_pin_q) (void)hipHostFree(idx->hs_pin_q);
@@ -254,12 +286,20 @@ extern "C" int rq_index_dim(const rq_index* idx) { return idx ? idx->dim : RQ_EI
 extern "C" int64_t rq_index_size(const rq_index* idx) { return idx ? idx->n : RQ_EINVAL; }
 extern "C" int rq_index_set_row_offset(rq_index* idx, int64_t off) {
     if (!idx || off < 0) return set_err(RQ_EINVAL, "bad row offset");
+    // keys carry the global row as a 32-bit field (0xffffffff is reserved): the whole shard must stay below it
+    if ((uint64_t)off + (uint64_t)idx->n >= 0xffffffffull) return set_err(RQ_EUNSUPPORTED, "row_offset %lld + %lld rows reaches 2^32-1: row ids are 32-bit inside keys", (long long)off, (long long)idx->n);
     idx->row_offset = off;
     return RQ_OK;
 }
 extern "C" int rq_index_reserve(rq_index* idx, int64_t n_rows) {
     if (!idx || n_rows < 0) return set_err(RQ_EINVAL, "bad reserve");
-    if (int r = use_device(idx)) return r;
+    if (!idx->shards.empty()) {
+        const int64_t g = (int64_t)idx->shards.size();
+        for (rq_index* c : idx->shards)
+            if (int r = rq_index_reserve(c, (n_rows + g - 1) / g)) return r;
+        return RQ_OK;
+    }
+    RQ_ON_DEVICE(idx);
     return grow(idx, n_rows);
 }
 
@@ -274,14 +314,16 @@ static int finish_add(rq_index* idx, int64_t n_new) {
     HIPCHK(hipStreamSynchronize(s));
     idx->max_row_norm = st[0]; idx->max_sub_rel = st[1]; idx->max_sub_abs = st[2];
     idx->n = e;
-    if ((uint64_t)(idx->row_offset + idx->n) >= 0xffffffffull) return set_err(RQ_EUNSUPPORTED, "row ids beyond 2^32-1 are not supported");
     return RQ_OK;
 }
 
 static int add_device_common(rq_index* idx, const void* d_rows, int64_t n_rows, bool is_f32, int normalize) {
     if (!idx || (!d_rows && n_rows > 0) || n_rows < 0) return set_err(RQ_EINVAL, "bad add arguments");
+    if (!idx->shards.empty()) return set_err(RQ_EUNSUPPORTED, "device-pointer appends on a multi-device index: use rq_index_add_f16 / _f32 (host rows)");
     if (n_rows == 0) return RQ_OK;
-    if (int r = use_device(idx)) return r;
+    if ((uint64_t)idx->row_offset + (uint64_t)idx->n + (uint64_t)n_rows >= 0xffffffffull)   // checked BEFORE anything is appended
+        return set_err(RQ_EUNSUPPORTED, "row ids beyond 2^32-1 are not supported (row_offset %lld + %lld rows)", (long long)idx->row_offset, (long long)(idx->n + n_rows));
+    RQ_ON_DEVICE(idx);
     // The rows may have been produced on any stream of the caller (e.g. torch's): wait for all of it.
     // Appending is not a hot path; searches in flight on other streams are drained too, which also
     // makes it safe to reallocate the shard below.
@@ -299,10 +341,13 @@ extern "C" int rq_index_add_f32_device(rq_index* idx, const float* d_rows, int64
     return add_device_common(idx, d_rows, n_rows, true, normalize);
 }
 
+static int multi_add(rq_index* idx, const void* rows, int64_t n_rows, bool is_f32, int normalize);
+
 static int add_host_common(rq_index* idx, const void* rows, int64_t n_rows, bool is_f32, int normalize) {
     if (!idx || (!rows && n_rows > 0) || n_rows < 0) return set_err(RQ_EINVAL, "bad add arguments");
     if (n_rows == 0) return RQ_OK;
-    if (int r = use_device(idx)) return r;
+    if (!idx->shards.empty()) return multi_add(idx, rows, n_rows, is_f32, normalize);
+    RQ_ON_DEVICE(idx);
     if (int r = grow(idx, idx->n + n_rows)) return r;
     // stream the host rows through a bounded device staging buffer
     const size_t esz = is_f32 ? 4 : 2;
@@ -324,10 +369,13 @@ extern "C" int rq_index_add_f32(rq_index* idx, const float* rows, int64_t n_rows
     return add_host_common(idx, rows, n_rows, true, normalize);
 }
 
+static int multi_get_rows(const rq_index* idx, int64_t row_begin, int64_t n_rows, uint16_t* out);
+
 extern "C" int rq_index_get_rows_f16(const rq_index* idx, int64_t row_begin, int64_t n_rows, uint16_t* out) {
     if (!idx || !out || row_begin < 0 || n_rows < 0 || row_begin + n_rows > idx->n) return set_err(RQ_EINVAL, "row range outside the index");
     if (n_rows == 0) return RQ_OK;
-    if (int r = use_device(idx)) return r;
+    if (!idx->shards.empty()) return multi_get_rows(idx, row_begin, n_rows, out);
+    RQ_ON_DEVICE(idx);
     HIPCHK(hipMemcpy2D(out, (size_t)idx->dim * 2, idx->x + (size_t)row_begin * RQ_DPAD * 2, (size_t)RQ_DPAD * 2, (size_t)idx->dim * 2,
                        (size_t)n_rows, hipMemcpyDeviceToHost));
     return RQ_OK;
@@ -336,6 +384,11 @@ extern "C" int rq_index_get_rows_f16(const rq_index* idx, int64_t row_begin, int
 // ---- options ---------------------------------------------------------------------------------
 extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     if (!idx || !name) return set_err(RQ_EINVAL, "bad option call");
+    if (!idx->shards.empty()) {
+        for (rq_index* c : idx->shards)
+            if (int r = rq_set_option(c, name, v)) return r;
+        return RQ_OK;
+    }
     const std::string s(name);
     if (s == "ring") { if (v < 2 || v > 6) return set_err(RQ_EINVAL, "ring must be 2..6"); idx->ring = (int)v; }
     else if (s == "wide_batch") { if (v < 0 || v > 3) return set_err(RQ_EINVAL, "wide_batch must be 0..3"); idx->wide_batch = (int)v; }
@@ -360,6 +413,13 @@ extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
 }
 extern "C" double rq_get_option(const rq_index* idx, const char* name) {
     if (!idx || !name) return NAN;
+    if (!idx->shards.empty()) {   // the statistics are shard maxima, everything else is the same on every child
+        double v = rq_get_option(idx->shards[0], name);
+        const std::string o(name);
+        if (o.rfind("max_", 0) == 0 || o.rfind("eps_", 0) == 0)
+            for (rq_index* c : idx->shards) v = std::max(v, rq_get_option(c, name));
+        return v;
+    }
     const std::string s(name);
     if (s == "ring") return idx->ring;
     if (s == "prefetch") return idx->prefetch;
@@ -474,11 +534,32 @@ static int flush_tails(rq_index* idx, hipStream_t s) {
 
 static int flush_all(rq_index* idx) {
     if (idx->ctx.empty()) return RQ_OK;
-    if (int r = use_device(idx)) return r;
+    RQ_ON_DEVICE(idx);
     for (auto& kv : idx->ctx)
         if (kv.second.fused_pending)
             if (int r = flush_tails(idx, kv.first)) return r;
     return RQ_OK;
+}
+
+static void free_ctx(StreamCtx& c);
+
+// Drop the workspace of `only` (or of every stream when all = true) after the device has drained.
+static int release_contexts(rq_index* idx, hipStream_t only, bool all) {
+    if (int r = flush_all(idx)) return r;
+    HIPCHK(hipDeviceSynchronize());
+    for (auto it = idx->ctx.begin(); it != idx->ctx.end();) {
+        if (all || it->first == only) { free_ctx(it->second); it = idx->ctx.erase(it); }
+        else ++it;
+    }
+    return RQ_OK;
+}
+
+extern "C" int rq_stream_release(rq_index* idx, void* stream) {
+    if (!idx) return set_err(RQ_EINVAL, "null index");
+    if (!idx->shards.empty()) return RQ_OK;
+    RQ_ON_DEVICE(idx);
+    if (idx->ctx.find((hipStream_t)stream) == idx->ctx.end()) return RQ_OK;
+    return release_contexts(idx, (hipStream_t)stream, false);
 }
 
 // One pass of the pipeline for B queries.  nb < 0: exact scan (every bin re-scored, no corpus scan).
@@ -516,6 +597,10 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     const int m = nb + 1;   // generic tail: bins re-scored + the first one that is not
     const bool fast = !exact && !force_generic && idx->fast_tail && k <= RQ_FAST_MAX_K;
     const int64_t ncand = fast ? (int64_t)RQ_CAND_CAP : (int64_t)nb * binrows;
+    // Workspaces are kept per caller stream.  A caller that keeps creating streams (torch hands out a pool of 32) would
+    // pile them up: beyond RQ_MAX_STREAM_CTX streams everything idle is dropped (rare; costs one device synchronisation).
+    if (idx->ctx.find(s) == idx->ctx.end() && idx->ctx.size() >= RQ_MAX_STREAM_CTX)
+        if (int r = release_contexts(idx, nullptr, true)) return r;
     StreamCtx& cx = idx->ctx[s];
     const bool piped = fast && may_defer && idx->pipeline == 1;
     // fused mode: one scan launch per call (<= 64 queries), which carries the tail of the previous call
@@ -670,7 +755,9 @@ extern "C" int rq_search_device(rq_index* idx, const float* d_queries, int B, in
                                 uint64_t* d_keys, int* d_status, void* stream) {
     if (int r = check_search_args(idx, d_queries, B, k, metric, d_scores, d_rows)) return r;
     if (!d_status) return set_err(RQ_EINVAL, "d_status is required");
-    if (int r = use_device(idx)) return r;
+    if (!idx->shards.empty()) return set_err(RQ_EUNSUPPORTED, "device-pointer searches on a multi-device index: use rq_search (host buffers), or one index per device");
+    if (!idx->shards.empty()) return set_err(RQ_EUNSUPPORTED, "device-pointer searches on a multi-device index: use rq_search (host buffers), or one index per device");
+    RQ_ON_DEVICE(idx);
     idx->t.searches++;
     idx->t.queries += B;
     return run_pipeline(idx, d_queries, B, k, metric, nb_default(idx, k), d_scores, d_rows, d_keys, d_status, (hipStream_t)stream, true);
@@ -678,7 +765,8 @@ extern "C" int rq_search_device(rq_index* idx, const float* d_queries, int B, in
 
 extern "C" int rq_search_flush_device(rq_index* idx, void* stream) {
     if (!idx) return set_err(RQ_EINVAL, "null index");
-    if (int r = use_device(idx)) return r;
+    if (!idx->shards.empty()) return RQ_OK;
+    RQ_ON_DEVICE(idx);
     return flush_tails(idx, (hipStream_t)stream);
 }
 
@@ -686,7 +774,9 @@ extern "C" int rq_search_fixup_device(rq_index* idx, const float* d_queries, int
                                       int64_t* d_rows, uint64_t* d_keys, int* d_status, void* stream) {
     if (int r = check_search_args(idx, d_queries, B, k, metric, d_scores, d_rows)) return r;
     if (!d_status) return set_err(RQ_EINVAL, "d_status is required");
-    if (int r = use_device(idx)) return r;
+    if (!idx->shards.empty()) return set_err(RQ_EUNSUPPORTED, "device-pointer searches on a multi-device index: use rq_search (host buffers), or one index per device");
+    if (!idx->shards.empty()) return set_err(RQ_EUNSUPPORTED, "device-pointer searches on a multi-device index: use rq_search (host buffers), or one index per device");
+    RQ_ON_DEVICE(idx);
     hipStream_t s = (hipStream_t)stream;
     if (int r = flush_tails(idx, s)) return r;
     std::vector<int> st((size_t)B);
@@ -752,9 +842,11 @@ extern "C" int rq_search_fixup_device(rq_index* idx, const float* d_queries, int
     return repaired;
 }
 
-extern "C" int rq_search(rq_index* idx, const float* queries, int B, int k, int metric, float* out_scores, int64_t* out_rows) {
-    if (int r = check_search_args(idx, queries, B, k, metric, out_scores, out_rows)) return r;
-    if (int r = use_device(idx)) return r;
+// The blocking host-buffer search in two halves, so that a multi-device parent can enqueue on every device before it
+// waits for any: search_begin stages the queries and enqueues the search on the index's own stream, search_end waits,
+// repairs uncertified queries and hands the results over.
+static int search_begin(rq_index* idx, const float* queries, int B, int k, int metric) {
+    RQ_ON_DEVICE(idx);
     if (B > idx->h_bcap || k > idx->h_kcap) {
         const int nb = std::max(B, idx->h_bcap), nk = std::max(k, idx->h_kcap);
         if (int r = ensure(idx->h_dq, (size_t)nb * RQ_MAX_DIM)) return r;
@@ -764,7 +856,8 @@ extern "C" int rq_search(rq_index* idx, const float* queries, int B, int k, int 
         idx->h_bcap = nb; idx->h_kcap = nk;
     }
     hipStream_t s = idx->own_stream;
-    if ((size_t)B * k <= 65536) {
+    idx->hs_small = (size_t)B * k <= 65536;
+    if (idx->hs_small) {
         // one device block [rows int64 | scores fp32 | status int32] -> one copy into pinned memory -> one synchronisation
         const size_t off_s = (size_t)B * k * sizeof(int64_t), off_t = off_s + (size_t)B * k * sizeof(float);
         const size_t bytes = off_t + (size_t)B * sizeof(int), qfloats = (size_t)B * idx->dim;
@@ -790,6 +883,20 @@ extern "C" int rq_search(rq_index* idx, const float* queries, int B, int k, int 
         if (int r = rq_search_device(idx, idx->h_dq, B, k, metric, d_scores, d_rows, nullptr, d_status, s)) return r;
         if (int r = flush_tails(idx, s)) return r;   // (option "pipeline": the tail must have run before the copy)
         HIPCHK(hipMemcpyAsync(idx->hs_pin, idx->hs_dev, bytes, hipMemcpyDeviceToHost, s));
+        return RQ_OK;
+    }
+    HIPCHK(hipMemcpyAsync(idx->h_dq, queries, (size_t)B * idx->dim * sizeof(float), hipMemcpyHostToDevice, s));
+    return rq_search_device(idx, idx->h_dq, B, k, metric, idx->h_dscores, idx->h_drows, nullptr, idx->h_dstatus, s);
+}
+
+static int search_end(rq_index* idx, int B, int k, int metric, float* out_scores, int64_t* out_rows) {
+    RQ_ON_DEVICE(idx);
+    hipStream_t s = idx->own_stream;
+    if (idx->hs_small) {
+        const size_t off_s = (size_t)B * k * sizeof(int64_t), off_t = off_s + (size_t)B * k * sizeof(float);
+        int64_t* d_rows = (int64_t*)idx->hs_dev;
+        float* d_scores = (float*)(idx->hs_dev + off_s);
+        int* d_status = (int*)(idx->hs_dev + off_t);
         HIPCHK(hipStreamSynchronize(s));
         const int* st = (const int*)(idx->hs_pin + off_t);
         bool clean = true;
@@ -804,13 +911,108 @@ extern "C" int rq_search(rq_index* idx, const float* queries, int B, int k, int 
         std::memcpy(out_scores, idx->hs_pin + off_s, off_t - off_s);
         return RQ_OK;
     }
-    HIPCHK(hipMemcpyAsync(idx->h_dq, queries, (size_t)B * idx->dim * sizeof(float), hipMemcpyHostToDevice, s));
-    if (int r = rq_search_device(idx, idx->h_dq, B, k, metric, idx->h_dscores, idx->h_drows, nullptr, idx->h_dstatus, s)) return r;
     const int fr = rq_search_fixup_device(idx, idx->h_dq, B, k, metric, idx->h_dscores, idx->h_drows, nullptr, idx->h_dstatus, s);
     if (fr < 0) return fr;
     HIPCHK(hipMemcpyAsync(out_scores, idx->h_dscores, (size_t)B * k * sizeof(float), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(out_rows, idx->h_drows, (size_t)B * k * sizeof(int64_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    return RQ_OK;
+}
+
+static int multi_search(rq_index* idx, const float* queries, int B, int k, int metric, float* out_scores, int64_t* out_rows);
+
+extern "C" int rq_search(rq_index* idx, const float* queries, int B, int k, int metric, float* out_scores, int64_t* out_rows) {
+    if (int r = check_search_args(idx, queries, B, k, metric, out_scores, out_rows)) return r;
+    if (!idx->shards.empty()) return multi_search(idx, queries, B, k, metric, out_scores, out_rows);
+    if (int r = search_begin(idx, queries, B, k, metric)) return r;
+    return search_end(idx, B, k, metric, out_scores, out_rows);
+}
+
+// ---------------------------------------------------------------------------------------------
+// multi-device parent: contiguous row blocks per device inside the library
+// ---------------------------------------------------------------------------------------------
+static rq_index* multi_create(int dim, int n_devices, const int* device_ids) {
+    rq_index* p = new rq_index();
+    p->dim = dim;
+    p->device = device_ids[0];
+    for (int j = 0; j < n_devices; ++j) {
+        rq_index* c = rq_index_create(dim, 1, device_ids + j);   // (the same device may be named several times)
+        if (!c) { rq_index_destroy(p); return nullptr; }
+        p->shards.push_back(c);
+        p->seg_local.push_back({0});
+        p->seg_global.push_back({});
+    }
+    return p;
+}
+
+static int multi_add(rq_index* idx, const void* rows, int64_t n_rows, bool is_f32, int normalize) {
+    if ((uint64_t)idx->row_offset + (uint64_t)idx->n + (uint64_t)n_rows >= 0xffffffffull)
+        return set_err(RQ_EUNSUPPORTED, "row ids beyond 2^32-1 are not supported");
+    const int64_t g = (int64_t)idx->shards.size(), per = (n_rows + g - 1) / g;
+    const size_t esz = is_f32 ? 4 : 2;
+    for (int64_t j = 0; j < g; ++j) {
+        const int64_t lo = std::min(j * per, n_rows), hi = std::min((j + 1) * per, n_rows);
+        if (hi <= lo) continue;
+        if (int r = add_host_common(idx->shards[j], (const char*)rows + (size_t)lo * idx->dim * esz, hi - lo, is_f32, normalize)) {
+            // pieces 0..j-1 of this block are already stored: the parent is no longer a prefix of what the caller sent
+            return set_err(r, "multi-device append failed on device slot %lld after %lld of %lld rows of the block were stored: %s",
+                           (long long)j, (long long)lo, (long long)n_rows, std::string(g_err).c_str());
+        }
+        idx->seg_global[j].push_back(idx->n + lo);
+        idx->seg_local[j].push_back(idx->seg_local[j].back() + (hi - lo));
+    }
+    idx->n += n_rows;
+    return RQ_OK;
+}
+
+static int multi_get_rows(const rq_index* idx, int64_t row_begin, int64_t n_rows, uint16_t* out) {
+    const int64_t row_end = row_begin + n_rows;
+    for (size_t j = 0; j < idx->shards.size(); ++j)
+        for (size_t sgi = 0; sgi < idx->seg_global[j].size(); ++sgi) {
+            const int64_t g0 = idx->seg_global[j][sgi], len = idx->seg_local[j][sgi + 1] - idx->seg_local[j][sgi];
+            const int64_t lo = std::max(g0, row_begin), hi = std::min(g0 + len, row_end);
+            if (hi <= lo) continue;
+            if (int r = rq_index_get_rows_f16(idx->shards[j], idx->seg_local[j][sgi] + (lo - g0), hi - lo, out + (size_t)(lo - row_begin) * idx->dim)) return r;
+        }
+    return RQ_OK;
+}
+
+static int multi_search(rq_index* idx, const float* queries, int B, int k, int metric, float* out_scores, int64_t* out_rows) {
+    const size_t g = idx->shards.size();
+    idx->t.searches++;
+    idx->t.queries += B;
+    std::vector<size_t> live;
+    for (size_t j = 0; j < g; ++j)
+        if (idx->shards[j]->n > 0) {
+            if (int r = search_begin(idx->shards[j], queries, B, k, metric)) return r;   // every device is busy before any is waited for
+            live.push_back(j);
+        }
+    std::vector<float> sc((size_t)B * k);
+    std::vector<int64_t> rw((size_t)B * k);
+    std::vector<std::vector<uint64_t>> keys((size_t)B);
+    for (size_t j : live) {
+        if (int r = search_end(idx->shards[j], B, k, metric, sc.data(), rw.data())) return r;
+        const std::vector<int64_t>& sl = idx->seg_local[j];
+        const std::vector<int64_t>& sg = idx->seg_global[j];
+        for (int q = 0; q < B; ++q)
+            for (int i = 0; i < k; ++i) {
+                const int64_t lr = rw[(size_t)q * k + i];
+                if (lr < 0) continue;
+                const size_t sgi = (size_t)(std::upper_bound(sl.begin(), sl.end() - 1, lr) - sl.begin()) - 1;   // segment that holds the local row
+                const int64_t grow = sg[sgi] + (lr - sl[sgi]);
+                keys[(size_t)q].push_back(rq_make_key(sc[(size_t)q * k + i], (uint32_t)grow));
+            }
+    }
+    for (int q = 0; q < B; ++q) {   // canonical order: score descending, then global row ascending = key descending
+        std::vector<uint64_t>& kq = keys[(size_t)q];
+        const size_t m = std::min<size_t>((size_t)k, kq.size());
+        std::partial_sort(kq.begin(), kq.begin() + m, kq.end(), std::greater<uint64_t>());
+        for (int i = 0; i < k; ++i) {
+            const bool v = (size_t)i < m;
+            out_scores[(size_t)q * k + i] = v ? rq_key_score(kq[(size_t)i]) : 0.f;
+            out_rows[(size_t)q * k + i] = v ? idx->row_offset + (int64_t)rq_key_index(kq[(size_t)i]) : -1;
+        }
+    }
     return RQ_OK;
 }
 
@@ -824,7 +1026,8 @@ extern "C" int rq_merge_keys_device(const uint64_t* d_keys_in, int n_per_query, 
 // ---- development hook: wall-clock (start, end) stamps of every workgroup of the LAST fused launch ------------
 extern "C" int rq_debug_stamps(rq_index* idx, int enable, unsigned long long* out, int max_wgs) {
     if (!idx) return set_err(RQ_EINVAL, "null index");
-    if (int r = use_device(idx)) return r;
+    if (!idx->shards.empty()) return set_err(RQ_EUNSUPPORTED, "debug hooks work on single-device indexes");
+    RQ_ON_DEVICE(idx);
     HIPCHK(hipDeviceSynchronize());
     if (enable && !idx->dbg_stamps) { HIPCHK(hipMalloc((void**)&idx->dbg_stamps, 4 * 8192 * sizeof(unsigned long long))); HIPCHK(hipMemset(idx->dbg_stamps, 0, 4 * 8192 * sizeof(unsigned long long))); }
     if (out && idx->dbg_stamps) HIPCHK(hipMemcpy(out, idx->dbg_stamps, (size_t)4 * std::min(max_wgs, 8192) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -834,8 +1037,9 @@ extern "C" int rq_debug_stamps(rq_index* idx, int enable, unsigned long long* ou
 
 // ---- measurement hook: plain streaming read of the shard (see rq_read_probe_kernel) ------------------------
 extern "C" double rq_debug_read_bandwidth(rq_index* idx, int iters, int nt, int wg_per_cu) {
-    if (!idx || iters < 1 || iters > 1000 || wg_per_cu < 1 || wg_per_cu > 32) { set_err(RQ_EINVAL, "bad arguments"); return -1.0; }
-    if (use_device(idx)) return -1.0;
+    if (!idx || iters < 1 || iters > 1000 || wg_per_cu < 1 || wg_per_cu > 32 || !idx->shards.empty()) { set_err(RQ_EINVAL, "bad arguments"); return -1.0; }
+    DeviceGuard dg_(idx->device);
+    if (!dg_.ok) { set_err(RQ_EHIP, "cannot select device %d", idx->device); return -1.0; }
     if (idx->n == 0) { set_err(RQ_EINVAL, "empty index"); return -1.0; }
     if (flush_all(idx)) return -1.0;
     const int64_t bytes = idx->n * (int64_t)(RQ_DPAD * 2);
@@ -866,8 +1070,8 @@ extern "C" double rq_debug_read_bandwidth(rq_index* idx, int iters, int nt, int 
 
 // ---- test hook: the scan's per-bin maxima of the last search on `stream` ---------------------------------
 extern "C" int64_t rq_debug_pooled(rq_index* idx, void* stream, int query, float* out, int64_t max_bins) {
-    if (!idx || !out || query < 0) return set_err(RQ_EINVAL, "bad arguments");
-    if (int r = use_device(idx)) return r;
+    if (!idx || !out || query < 0 || !idx->shards.empty()) return set_err(RQ_EINVAL, "bad arguments");
+    RQ_ON_DEVICE(idx);
     auto it = idx->ctx.find((hipStream_t)stream);
     if (it == idx->ctx.end() || !it->second.w[0].bins || query >= it->second.w[0].bcap) return set_err(RQ_EINVAL, "no search has run on this stream");
     const Workspace& w = it->second.w[0];
@@ -884,7 +1088,18 @@ extern "C" int64_t rq_debug_pooled(rq_index* idx, void* stream, int query, float
 // ---- timing ----------------------------------------------------------------------------------
 extern "C" int rq_get_timing(rq_index* idx, rq_timing* out) {
     if (!idx || !out) return set_err(RQ_EINVAL, "null argument");
-    if (int r = use_device(idx)) return r;
+    if (!idx->shards.empty()) {   // kernel figures summed over the children, call counts of the parent
+        rq_timing sum = idx->t;
+        for (rq_index* c : idx->shards) {
+            rq_timing t;
+            if (int r = rq_get_timing(c, &t)) return r;
+            sum.scan_ms += t.scan_ms; sum.scan_launches += t.scan_launches; sum.scan_bytes += t.scan_bytes;
+            sum.widened += t.widened; sum.exact_scans += t.exact_scans;
+        }
+        *out = sum;
+        return RQ_OK;
+    }
+    RQ_ON_DEVICE(idx);
     HIPCHK(hipDeviceSynchronize());
     double ms = 0.0;
     for (size_t i = 0; i < idx->ev_used; ++i) {
@@ -900,7 +1115,13 @@ extern "C" int rq_get_timing(rq_index* idx, rq_timing* out) {
 }
 extern "C" int rq_reset_timing(rq_index* idx) {
     if (!idx) return set_err(RQ_EINVAL, "null argument");
-    if (int r = use_device(idx)) return r;
+    if (!idx->shards.empty()) {
+        idx->t = rq_timing{};
+        for (rq_index* c : idx->shards)
+            if (int r = rq_reset_timing(c)) return r;
+        return RQ_OK;
+    }
+    RQ_ON_DEVICE(idx);
     HIPCHK(hipDeviceSynchronize());
     idx->ev_used = 0;
     idx->t = rq_timing{};
@@ -910,7 +1131,7 @@ extern "C" int rq_reset_timing(rq_index* idx) {
 // ---- persistence -----------------------------------------------------------------------------
 extern "C" int rq_save(const rq_index* idx, const char* path) {
     if (!idx || !path) return set_err(RQ_EINVAL, "null argument");
-    if (int r = use_device(idx)) return r;
+    RQ_ON_DEVICE(idx);
     const std::string meta = std::string(path) + ".meta", data = std::string(path) + ".f16";
     FILE* f = fopen(data.c_str(), "wb");
     if (!f) return set_err(RQ_EIO, "cannot write %s", data.c_str());

@@ -124,82 +124,15 @@ def gather_merge_host(local_scores: np.ndarray, local_rows: np.ndarray, k: int, 
     return merge_keys_host(allk, k)
 
 
-class MultiDeviceIndex:
-    """Row shards on several GPUs of ONE process, merged on the host (the in-process counterpart of
-    ShardedDenseSearcher; same duck type as _native.NativeIndex for add_f32 / add_f16 / search / __len__).
+class MultiDeviceIndex(_native.NativeIndex):
+    """Row shards on several GPUs of ONE process (the in-process counterpart of ShardedDenseSearcher).
 
-    Every appended block is cut into len(devices) contiguous pieces, piece j goes to shard j.  A shard
-    therefore holds several global-id segments; device results carry local rows and are mapped back on the
-    host (`_to_global`) before the canonical merge.  Local order inside a shard is monotone in the global
-    id, so the per-shard tie-break (row ascending) is the global one.
-    """
+    Since round 2 this is the library's own multi-device index (`rq_index_create(dim, n_devices, device_ids)`,
+    include/rq.h): contiguous pieces of every appended block per device, one stream per device, every device enqueued
+    before any is waited for, k keys per shard copied back, canonical host merge -- all inside librq_hip.so.  The class
+    is kept as the name `DenseIndex(devices=[...])` constructs."""
 
     def __init__(self, dim: int, devices: Sequence[int]):
-        import torch
-
         if not devices:
             raise ValueError("devices must name at least one GPU")
-        self.torch = torch
-        self.dim = int(dim)
-        self.devices = [int(d) for d in devices]
-        self.shards = [_native.NativeIndex(dim, d) for d in self.devices]
-        self._seg_local = [[0] for _ in self.devices]      # per shard: local start of each segment (+ end sentinel)
-        self._seg_global = [[] for _ in self.devices]      # per shard: global start of each segment
-        self._n = 0
-
-    def __len__(self) -> int:
-        return self._n
-
-    def close(self) -> None:
-        for s in self.shards:
-            s.close()
-
-    def _append(self, rows: np.ndarray, add) -> None:
-        n = rows.shape[0]
-        g = len(self.shards)
-        per = (n + g - 1) // g
-        for j, shard in enumerate(self.shards):
-            lo, hi = min(j * per, n), min((j + 1) * per, n)
-            if hi > lo:
-                add(shard, rows[lo:hi])
-                self._seg_global[j].append(self._n + lo)
-                self._seg_local[j].append(self._seg_local[j][-1] + (hi - lo))
-        self._n += n
-
-    def add_f32(self, rows: np.ndarray, normalize: bool = True) -> None:
-        self._append(np.ascontiguousarray(rows, dtype=np.float32), lambda sh, r: sh.add_f32(r, normalize))
-
-    def add_f16(self, rows: np.ndarray) -> None:
-        self._append(np.ascontiguousarray(rows), lambda sh, r: sh.add_f16(r))
-
-    def _to_global(self, j: int, local_rows: np.ndarray) -> np.ndarray:
-        starts = np.asarray(self._seg_local[j][:-1], dtype=np.int64)
-        gstarts = np.asarray(self._seg_global[j], dtype=np.int64)
-        seg = np.clip(np.searchsorted(starts, local_rows, side="right") - 1, 0, max(len(starts) - 1, 0))
-        out = np.where(local_rows >= 0, gstarts[seg] + (local_rows - starts[seg]), -1) if len(starts) else np.full_like(local_rows, -1)
-        return out
-
-    def search(self, queries: np.ndarray, k: int, metric: int = _native.METRIC_COSINE) -> Tuple[np.ndarray, np.ndarray]:
-        torch = self.torch
-        q = np.ascontiguousarray(np.atleast_2d(queries), dtype=np.float32)
-        B = q.shape[0]
-        work = []
-        for j, shard in enumerate(self.shards):            # enqueue every shard before waiting for any
-            if len(shard) == 0:
-                continue
-            dev = torch.device("cuda", self.devices[j])
-            with torch.cuda.device(dev):
-                st = torch.cuda.Stream(device=dev)
-                dq = torch.from_numpy(q).to(dev, non_blocking=False)
-                sc = torch.empty((B, k), device=dev); rw = torch.empty((B, k), device=dev, dtype=torch.int64)
-                status = torch.empty((B,), device=dev, dtype=torch.int32)
-                shard.search_device(dq, B, k, metric, sc, rw, None, status, st.cuda_stream)
-                work.append((j, shard, dq, sc, rw, status, st))
-        parts = []
-        for j, shard, dq, sc, rw, status, st in work:
-            shard.search_fixup_device(dq, B, k, metric, sc, rw, None, status, st.cuda_stream)   # syncs the stream, repairs if needed
-            st.synchronize()
-            parts.append(pack_keys(sc.cpu().numpy(), self._to_global(j, rw.cpu().numpy())))
-        if not parts:
-            return np.zeros((B, k), np.float32), np.full((B, k), -1, np.int64)
-        return merge_keys_host(np.concatenate(parts, axis=1), k)
+        super().__init__(dim, devices=[int(d) for d in devices])

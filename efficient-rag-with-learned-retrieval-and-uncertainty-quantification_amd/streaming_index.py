@@ -391,8 +391,6 @@ class DenseIndex:
         docs_path, base = self._files()
         docs_path.parent.mkdir(parents=True, exist_ok=True)
         if self._index is not None:
-            if not hasattr(self._index, "save"):
-                raise NotImplementedError("persistence of a multi-device index: save each shard's rows with rq_save, or rebuild")
             self._index.save(str(base))
         with open(docs_path, "w") as f:
             for i, doc_id in enumerate(self._ids):
@@ -402,7 +400,7 @@ class DenseIndex:
         docs_path, base = self._files()
         if not Path(str(base) + ".meta").exists():
             return
-        self._index = _native.NativeIndex.load(str(base), self.device)
+        self._index = _native.NativeIndex.load(str(base), self.device, devices=self.devices)
         self.dim = self._index.dim
         with open(docs_path) as f:
             for line in f:

@@ -45,9 +45,15 @@ enum { RQ_METRIC_COSINE = 0, RQ_METRIC_IP = 1 };
 /* Number of visible HIP devices (0 if none / no driver). */
 int rq_device_count(void);
 
-/* Create an empty index of `dim`-element rows (1 <= dim <= RQ_MAX_DIM) on device_ids[0].
- * n_devices must be 1: one process per GPU; shards on other GPUs live in other processes and are
- * merged with rq_merge_keys_device.  NULL on error. */
+/* Create an empty index of `dim`-element rows (1 <= dim <= RQ_MAX_DIM).  NULL on error.
+ * n_devices == 1: one row shard on device_ids[0] (the form every *_device call works on; shards in other processes
+ *   are merged with rq_merge_keys_device).
+ * n_devices  > 1: the rows are sharded across device_ids[0..n_devices) inside the library: every appended block is cut
+ *   into n_devices contiguous pieces, piece j is stored on device_ids[j]; rq_search enqueues the search on every device
+ *   before it waits for any, copies each device's k best (score, row) pairs back and merges them on the host in the
+ *   canonical order.  Same rq_index_add_f16 / _f32, rq_search, rq_index_get_rows_f16, rq_save / rq_load, rq_set_option
+ *   calls; the device-pointer entry points (*_device) return RQ_EUNSUPPORTED on such an index.  A device may be named
+ *   more than once (several shards on one GPU). */
 rq_index* rq_index_create(int dim, int n_devices, const int* device_ids);
 void rq_index_destroy(rq_index* idx);
 
@@ -91,6 +97,10 @@ int rq_search_device(rq_index* idx, const float* d_queries, int B, int k, int me
  * (rq_search_fixup_device implies it); output buffers must stay valid until then.  Mode 1 also reads d_queries
  * until then, mode 2 keeps its own copy. */
 int rq_search_flush_device(rq_index* idx, void* stream);
+/* The library keeps one search workspace per caller stream (about 11 MB at 1M rows and 64 queries).  Call this before a
+ * stream that has been used for searches is destroyed, or when it will not be used again: waits for the device, runs
+ * any deferred tail, frees the stream's workspace.  (Beyond 8 streams the library drops idle workspaces by itself.) */
+int rq_stream_release(rq_index* idx, void* stream);
 /* Synchronises `stream`, re-runs the queries whose d_status is non-zero with wider candidate sets /
  * the exact scan, patches d_scores/d_rows/d_keys/d_status in place.  Returns the number repaired. */
 int rq_search_fixup_device(rq_index* idx, const float* d_queries, int B, int k, int metric, float* d_scores, int64_t* d_rows,
@@ -106,7 +116,11 @@ int rq_merge_keys_device(const uint64_t* d_keys_in, int n_per_query, int B, int 
  * "wg_per_cu", "nt" (non-temporal corpus loads: 0, 1, -1 = auto), "slack_bins" (extra bins beyond k, -1 = auto),
  * "eps" (certificate bound, <0 = derived default), "profile" (record HIP events around every scan launch; "profile_stride" n: around every n-th),
  * "prefetch" (LDS fragments read ahead of their MFMAs: 1, 4, 6, 12), "fast_tail" (0 = generic sorted tail),
- * "pipeline" (see rq_search_flush_device). */
+ * "pipeline" (see rq_search_flush_device), "wide_batch" (calls of more than 64 queries: 0 = passes of 64 only, 1 = passes of
+ * 256 / 128 / 64, 3 = 128 / 64, 2 = round 1's 8-wave 128-query pass), "wide128" / "wide256" (variant of csrc/rq_scan_wide.hip),
+ * "poison_cand" (test hook: candidate lists are filled with 0xff..ff keys before every tail).
+ * Read-only: "max_row_norm", "max_sub_rel" / "max_sub_abs" (largest share of a stored row that sits in fp16-subnormal elements,
+ * which the matrix cores flush), "eps_cosine" / "eps_ip" (the certificate's bound including that term). */
 int rq_set_option(rq_index* idx, const char* name, double value);
 double rq_get_option(const rq_index* idx, const char* name);
 

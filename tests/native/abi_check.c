@@ -33,6 +33,32 @@ int main(void) {
         return 1;
     }
     if (rq_search(idx, &q[0][0], 0, 3, RQ_METRIC_COSINE, &scores[0][0], &ids[0][0]) != RQ_EINVAL) { printf("B = 0 accepted\n"); return 1; }
+    /* the same rows sharded across three device slots inside the library (rq_index_create(dim, n_devices, ids));
+     * here the one GPU named three times.  Appended in two blocks, so every slot holds two segments of global ids. */
+    {
+        int devs[3] = {0, 0, 0};
+        rq_index* multi = rq_index_create(8, 3, devs);
+        if (!multi) { printf("multi-device create failed: %s\n", rq_last_error()); return 1; }
+        if (rq_index_add_f32(multi, &rows[0][0], 40, 1) != RQ_OK || rq_index_add_f32(multi, &rows[40][0], 60, 1) != RQ_OK || rq_index_size(multi) != 100) {
+            printf("multi-device add failed: %s\n", rq_last_error()); return 1;
+        }
+        float ms[2][3];
+        int64_t mi[2][3];
+        if (rq_search(multi, &q[0][0], 2, 3, RQ_METRIC_COSINE, &ms[0][0], &mi[0][0]) != RQ_OK) { printf("multi-device search failed: %s\n", rq_last_error()); return 1; }
+        if (memcmp(mi, ids, sizeof mi) != 0 || memcmp(ms, scores, sizeof ms) != 0) {
+            printf("multi-device result differs: %lld %f vs %lld %f\n", (long long)mi[0][0], ms[0][0], (long long)ids[0][0], scores[0][0]);
+            return 1;
+        }
+        uint16_t one[8], ref[8];
+        if (rq_index_get_rows_f16(multi, 57, 1, one) != RQ_OK || rq_index_get_rows_f16(idx, 57, 1, ref) != RQ_OK || memcmp(one, ref, sizeof one) != 0) {
+            printf("multi-device row read-back differs\n"); return 1;
+        }
+        if (rq_search_device(multi, &q[0][0], 2, 3, RQ_METRIC_COSINE, &ms[0][0], &mi[0][0], NULL, (int*)mi, NULL) != RQ_EUNSUPPORTED) {
+            printf("device-pointer search accepted on a multi-device index\n"); return 1;
+        }
+        rq_index_destroy(multi);
+    }
+    if (rq_stream_release(idx, NULL) != RQ_OK) { printf("stream release failed: %s\n", rq_last_error()); return 1; }
     rq_index_destroy(idx);
     printf("OK (device search)\n");
     return 0;

@@ -49,7 +49,9 @@ def test_no_device_means_loud_failure_not_fallback():
     ids = (ctypes.c_int * 1)(0)
     assert not lib.rq_index_create(768, 1, ids)
     assert not lib.rq_index_create(0, 1, ids) and "dim" in _native.last_error()
-    assert not lib.rq_index_create(768, 2, ids) and "one process per GPU" in _native.last_error()
+    two = (ctypes.c_int * 2)(0, 0)
+    assert not lib.rq_index_create(768, 2, two) and "no HIP device" in _native.last_error()      # multi-device: same loud failure
+    assert not lib.rq_index_create(768, 0, ids) and "n_devices" in _native.last_error()
     assert not lib.rq_load(b"/nonexistent/path", 1, ids)
 
 

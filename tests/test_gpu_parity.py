@@ -813,6 +813,65 @@ def test_multi_device_index_in_one_process():
         assert one.search(text, 25) == many.search(text, 25)
 
 
+def test_multi_device_index_persistence_and_row_offset(tmp_path):
+    """rq_index_create(n_devices = 3) inside the library: save -> load (again sharded, and as one shard), row offset,
+    read-back of rows that straddle segments, device-pointer entry points refused."""
+    x16 = orc.synthetic_corpus(5_003, 96, seed=53)
+    m = nat.NativeIndex(96, devices=[0, 0, 0])
+    m.add_f16(x16[:2_000]); m.add_f16(x16[2_000:])
+    assert len(m) == 5_003 and np.array_equal(m.get_rows_f16(600, 3_000).view(np.uint16), x16[600:3_600].view(np.uint16))
+    q = orc.synthetic_queries(9, 96, seed=54)
+    m.set_row_offset(10_000)
+    _check(m, x16, q, 12, row_offset=10_000)
+    m.set_row_offset(0)
+    m.save(str(tmp_path / "multi"))
+    for devs in ([0, 0], [0]):
+        back = nat.NativeIndex.load(str(tmp_path / "multi"), devices=devs)
+        assert len(back) == 5_003
+        _check(back, x16, q, 12)
+        back.close()
+    with pytest.raises(nat.RqError, match="multi-device"):
+        m.search_device(8, 1, 1, 0, 8, 8, None, 8)          # (dummy non-null addresses: refused before anything is touched)
+    assert m.timing()["queries"] == 9
+    m.close()
+
+
+def test_many_caller_streams_do_not_pile_up_workspaces():
+    """One search workspace per caller stream (csrc/rq_api.hip): 40 streams in a row must not keep 40 workspaces
+    (the library drops idle ones beyond 8), and rq_stream_release frees one explicitly."""
+    import torch
+    dev = torch.device("cuda:0")
+    x16 = orc.synthetic_corpus(100_000, 768, seed=12)
+    q = orc.synthetic_queries(64, 768, seed=13)
+    gs, gr = orc.dense_topk(q, x16, 10)
+    idx = nat.NativeIndex(768, 0)
+    idx.add_f16(x16)
+    dq = torch.from_numpy(q).to(dev)
+    sc = torch.empty((64, 10), device=dev); rw = torch.empty((64, 10), device=dev, dtype=torch.int64); st = torch.empty((64,), device=dev, dtype=torch.int32)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(40)]
+
+    def run(s):
+        idx.search_device(dq, 64, 10, 0, sc, rw, None, st, s.cuda_stream)
+        s.synchronize()
+        assert np.array_equal(rw.cpu().numpy(), gr)
+    for s in streams[:8]:
+        run(s)
+    torch.cuda.synchronize()
+    free8, _ = torch.cuda.mem_get_info(dev)
+    for s in streams[8:]:
+        run(s)
+    torch.cuda.synchronize()
+    free40, _ = torch.cuda.mem_get_info(dev)
+    assert free8 - free40 < 16 << 20, f"{(free8 - free40) >> 20} MiB more device memory after 32 further streams"
+    idx.set_option("pipeline", 2)
+    idx.search_device(dq, 64, 10, 0, sc, rw, None, st, streams[0].cuda_stream)     # a deferred tail is pending on this stream
+    rw.fill_(-5)
+    idx.stream_release(streams[0].cuda_stream)                                      # runs it, then drops the workspace
+    torch.cuda.synchronize()
+    assert np.array_equal(rw.cpu().numpy(), gr)
+    idx.close()
+
+
 @pytest.mark.parametrize("n,B", [(40_000, 64), (40_033, 64), (4_101, 64), (40_033, 128), (40_000, 256), (4_101, 256)])
 def test_scan_bin_maxima_within_certificate_eps(n, B):
     """The certificate assumes |approximate scan score - exact score| <= eps = 7e-4.  Read the
