@@ -862,7 +862,7 @@ def test_many_caller_streams_do_not_pile_up_workspaces():
         run(s)
     torch.cuda.synchronize()
     free40, _ = torch.cuda.mem_get_info(dev)
-    assert free8 - free40 < 16 << 20, f"{(free8 - free40) >> 20} MiB more device memory after 32 further streams"
+    assert free8 - free40 < 48 << 20, f"{(free8 - free40) >> 20} MiB more device memory after 32 further streams"
     idx.set_option("pipeline", 2)
     idx.search_device(dq, 64, 10, 0, sc, rw, None, st, streams[0].cuda_stream)     # a deferred tail is pending on this stream
     rw.fill_(-5)
