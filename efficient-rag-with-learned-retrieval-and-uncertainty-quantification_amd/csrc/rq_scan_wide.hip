@@ -51,7 +51,7 @@ __device__ __forceinline__ void rqw_insert(float& m1, float& m2, float& m3, floa
     m3 = n3; m2 = n2; m1 = n1;
 }
 
-template <bool NT, int D, int QW, int QG, int EPI, int DBG = 0>
+template <bool NT, int D, int QW, int QG, int EPI, int DBG = 0, int PRIO = 0>
 __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, const int G) {
     static_assert(D >= 2 && D <= 12 && 24 % D == 0, "prefetch distance");
     static_assert(QW == 4 || QW == 8, "waves per workgroup");
@@ -142,6 +142,8 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
         }
     };
 
+    // static priority for the second-dispatched half of an 8-wave workgroup (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+    if (PRIO == 1 && QW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
     rq_half8 av[D];   // fragment ring: fragment f of the quad lives in av[f % D]
     acquire(0);
 #pragma unroll
@@ -155,7 +157,23 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
 #pragma unroll
         for (int g = 0; g < QG; ++g) { m1[g] = NEG_INF; m2[g] = NEG_INF; m3[g] = NEG_INF; ap[g] = 0; }
         const char* nrow = norm_lds + ((lq & 1) << 8) + kg * 16;
-        rq_float4 acc[QG];
+        // accumulators alternate between two register sets by tile parity: with PRIO == 2 the waves 4..7 of an 8-wave
+        // workgroup run the selection of tile t after the first 12 MFMAs of tile t + 1 (tiles 0..2; tile 3's at the end of the
+        // quad), so that of the two waves that share a SIMD one is in its VALU epilogue while the other feeds the matrix
+        // core instead of both doing the same thing at the same time (MI355X_MICROARCH.md, two waves per SIMD, item 9)
+        rq_float4 acc2[2][QG];
+        const bool late = PRIO == 2 && QW == 8 && wave >= 4;
+        auto select_tile = [&](int t) {
+            const rq_float4 nv = *(const rq_float4*)(nrow + t * 64);
+#pragma unroll
+            for (int g = 0; g < QG; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float sc = rqw_med3(acc2[t & 1][g][i] * nv[i], -3.4028234664e38f, 3.4028234664e38f);
+                    const float x = __uint_as_float((__float_as_uint(sc) & 0xffffffc0u) | (uint32_t)(t * 16 + i));
+                    rqw_insert(m1[g], m2[g], m3[g], x);
+                }
+        };
 #pragma clang loop unroll(full)
         for (int t = 0; t < 4; ++t)
 #pragma clang loop unroll(full)
@@ -175,6 +193,7 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
                     av[f % D] = frag(0, r - 96);
                 }
             }
+            rq_float4 (&acc)[QG] = acc2[t & 1];
             if (s == 0) {
 #pragma unroll
                 for (int g = 0; g < QG; ++g) acc[g] = rq_float4{0.f, 0.f, 0.f, 0.f};
@@ -186,11 +205,15 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
 #pragma unroll
             for (int g = 0; g < QG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur, qf[g][s], acc[g], 0, 0, 0);
             }
+            if (PRIO == 2 && EPI == 1 && DBG == 0) {
+                if (s == 11 && t >= 1) { if (late) select_tile(t - 1); }
+                if (s == 23) { if (!late || t == 3) select_tile(t); }
+            }
             if (s == 23 && DBG == 1) {
 #pragma unroll
                 for (int g = 0; g < QG; ++g) m1[g] = fmaxf(m1[g], fmaxf(fmaxf(acc[g][0], acc[g][1]), fmaxf(acc[g][2], acc[g][3])));
             }
-            if (s == 23 && DBG != 1 && EPI == 1) {
+            if (s == 23 && DBG != 1 && EPI == 1 && PRIO != 2) {
                 // Tile epilogue, D[row = 4*kg + i][query = r16].  score = acc * row scale, clamped to the finite range (an
                 // infinite score stays the largest, NaN becomes the smallest); its 6 low mantissa bits are then REPLACED by
                 // the row's position in the quad (bits 4..5 tile, 0..1 register; the lane's row group 4*kg is OR-ed in
@@ -294,12 +317,12 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
 
 static constexpr size_t rq_scanw_lds_bytes(int QW, int QG) { return (size_t)4 * 24576 + 512 + (size_t)16 * QW * QG * rqw_sq(QW, QG) * 8; }
 
-template <bool NT, int D, int OCC, int QW, int QG, int EPI, int DBG>
+template <bool NT, int D, int OCC, int QW, int QG, int EPI, int DBG, int PRIO>
 __global__ __launch_bounds__(64 * QW, OCC) void rq_scanw_kernel(RqScanArgs a) {
-    rq_scanw_body<NT, D, QW, QG, EPI, DBG>(a, (int)blockIdx.x, (int)gridDim.x);
+    rq_scanw_body<NT, D, QW, QG, EPI, DBG, PRIO>(a, (int)blockIdx.x, (int)gridDim.x);
 }
 
-template <bool NT, int D, int OCC, int QW, int QG, int EPI = 0, int DBG = 0>
+template <bool NT, int D, int OCC, int QW, int QG, int EPI = 0, int DBG = 0, int PRIO = 0>
 static hipError_t rq_scanw_launch_t(const RqScanArgs& a, int grid, hipStream_t stream) {
     constexpr size_t lds = rq_scanw_lds_bytes(QW, QG);
     static_assert(lds <= 160 * 1024, "LDS of one workgroup");
@@ -308,11 +331,11 @@ static hipError_t rq_scanw_launch_t(const RqScanArgs& a, int grid, hipStream_t s
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (!((attr_done >> (dev & 63)) & 1ull)) {
-        e = hipFuncSetAttribute((const void*)rq_scanw_kernel<NT, D, OCC, QW, QG, EPI, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipFuncSetAttribute((const void*)rq_scanw_kernel<NT, D, OCC, QW, QG, EPI, DBG, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done |= 1ull << (dev & 63);
     }
-    hipLaunchKernelGGL((rq_scanw_kernel<NT, D, OCC, QW, QG, EPI, DBG>), dim3(grid), dim3(64 * QW), lds, stream, a);
+    hipLaunchKernelGGL((rq_scanw_kernel<NT, D, OCC, QW, QG, EPI, DBG, PRIO>), dim3(grid), dim3(64 * QW), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -323,6 +346,8 @@ static hipError_t rq_scanw_launch_t(const RqScanArgs& a, int grid, hipStream_t s
 //   3  256 queries: 8 waves x 2 groups, reads 3 ahead
 //   4  128 queries: as 1 with rq_scan.hip's compare/select epilogue (A/B of the selection forms)
 //   5  128 queries: 4 waves x 2 groups, one wave per SIMD (A/B: a lone wave cannot overlap its own VALU with its MFMAs)
+//   6  128 queries: as 0 with the selection of waves 4..7 staggered by half a tile;  7: as 0 with s_setprio 1 for waves 4..7
+//      (A/B of the two-waves-per-SIMD levers of MI355X_MICROARCH.md: neither beats 0 once the accumulators alternate)
 //   90..92  timing experiments on variant 4's shape, results invalid: no epilogue / no LDS reads / no MFMAs
 hipError_t rq_scan_wide_launch(const RqScanArgs& a, int variant, int queries, bool nt, int grid, hipStream_t stream) {
     if (grid <= 0) return hipErrorInvalidValue;
@@ -331,6 +356,7 @@ hipError_t rq_scan_wide_launch(const RqScanArgs& a, int variant, int queries, bo
         return nt ? rq_scanw_launch_t<true, DD, OO, QQ, GG, ##__VA_ARGS__>(a, grid, stream) : rq_scanw_launch_t<false, DD, OO, QQ, GG, ##__VA_ARGS__>(a, grid, stream);
     RQW_CASE(0, 12, 2, 8, 1, 1) RQW_CASE(1, 4, 2, 8, 1, 1) RQW_CASE(2, 2, 2, 8, 2, 1) RQW_CASE(3, 3, 2, 8, 2, 1)
     RQW_CASE(4, 4, 2, 8, 1, 0) RQW_CASE(5, 4, 1, 4, 2, 1)
+    RQW_CASE(6, 12, 2, 8, 1, 1, 0, 2) RQW_CASE(7, 12, 2, 8, 1, 1, 0, 1)
     RQW_CASE(90, 4, 2, 8, 1, 0, 1) RQW_CASE(91, 4, 2, 8, 1, 0, 2) RQW_CASE(92, 4, 2, 8, 1, 0, 3)
 #undef RQW_CASE
     return hipErrorInvalidValue;

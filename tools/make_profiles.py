@@ -35,7 +35,7 @@ if ks1:
         w.writeheader()
         w.writerows([r for r in rows if "rq_" in r["Name"]])
     print("single-stream kernel stats:", [(r["Name"][:40], r["Calls"], round(float(r["AverageNs"]) / 1e3, 1)) for r in rows if "rq_" in r["Name"]][:4])
-for logname in ("bench2", "prof_bench", "prof_bench_1s"):
+for logname in ("bench2", "bench20", "prof_bench", "prof_bench_1s"):
     lp = os.path.join(ROOT, "gpurun_out", logname + ".log")
     if os.path.exists(lp):
         lines = [l for l in open(lp, errors="replace").read().splitlines() if l.startswith('{"metric"')]
@@ -43,6 +43,36 @@ for logname in ("bench2", "prof_bench", "prof_bench_1s"):
             open(os.path.join(out, f"{tag}_{logname}.json"), "w").write(lines[-1] + "\n")
             d = json.loads(lines[-1])
             print(logname, "value", round(d["value"]), "ms/step", round(d["ms_per_step"], 4), "scan avg us", round(d["roofline"]["avg_launch_us"], 1), "frac", round(d["roofline"]["frac"], 3))
+
+# ---- matrix-core counters of the fused scan + tail launch -> achieved fp16 FLOP/s against the dense peak
+mf = first("pmc_mfma/*/*counter_collection.csv")
+if mf:
+    acc = {}
+    for r in csv.DictReader(open(mf)):
+        if "rq_scan_tail" in r["Kernel_Name"]:
+            acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    mean = {k: sum(v) / len(v) for k, v in acc.items()}
+    dur_us = None
+    if ks:
+        for r in csv.DictReader(open(ks)):
+            if "rq_scan_tail" in r["Name"]:
+                dur_us = float(r["AverageNs"]) / 1e3
+    if "SQ_INSTS_VALU_MFMA_MOPS_F16" in mean and dur_us:
+        flop = mean["SQ_INSTS_VALU_MFMA_MOPS_F16"] * 512.0        # one MOP = 512 FLOP (a 16x16x32 MFMA = 16384 FLOP = 32 MOPs)
+        algo_flop = 2.0 * 64 * 1_000_000 * 768
+        gui = mean.get("GRBM_GUI_ACTIVE", 0.0) / 8.0                # summed over the 8 XCDs
+        summ = {"kernel": "rq_scan_tail_kernel", "workload": "1000000x768 fp16 corpus, 64 queries per launch",
+                "counters_mean_per_launch": mean, "launches": len(next(iter(acc.values()))),
+                "avg_launch_us_from_kernel_stats": dur_us,
+                "mfma_flop_per_launch": flop, "algorithmic_flop_per_launch": algo_flop, "flop_over_algorithmic": flop / algo_flop,
+                "achieved_TFLOPs": flop / (dur_us * 1e-6) / 1e12, "dense_fp16_peak_TFLOPs": 2500.0,
+                "mfma_frac_of_peak": flop / (dur_us * 1e-6) / 1e12 / 2500.0,
+                "mfma_busy_frac": (mean.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * gui)) if gui else None,
+                "note": "SQ_VALU_MFMA_BUSY_CYCLES counts 16 cycles per v_mfma_f32_16x16x32_f16, summed over the 1024 SIMDs; GRBM_GUI_ACTIVE / 8 = "
+                        "shader cycles of the launch.  The kernel is HBM-bound (64 FLOP per corpus byte against a machine balance of ~310): "
+                        "the matrix cores are the means not to be ALU-bound, not the roofline."}
+        json.dump(summ, open(os.path.join(out, f"{tag}_pmc_mfma.json"), "w"), indent=1)
+        print("mfma:", {k: summ[k] for k in ("achieved_TFLOPs", "mfma_frac_of_peak", "mfma_busy_frac", "flop_over_algorithmic")})
 
 pmc = {}
 for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
