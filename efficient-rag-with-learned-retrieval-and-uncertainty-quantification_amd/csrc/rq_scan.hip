@@ -284,7 +284,7 @@ hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int ks, int qw, bo
     RQ_CASE(3, 1, 3, 2, 4) RQ_CASE(4, 1, 3, 2, 4)
     RQ_CASE(4, 4, 2, 2, 4) RQ_CASE(6, 4, 2, 2, 4)
     RQ_CASE(5, 6, 2, 2, 4) RQ_CASE(6, 12, 2, 2, 4)
-    RQ_CASE(2, 4, 2, 1, 4) RQ_CASE(3, 4, 2, 1, 4) RQ_CASE(3, 12, 2, 1, 4) RQ_CASE(2, 1, 3, 1, 4) RQ_CASE(4, 4, 2, 1, 4)
+    RQ_CASE(2, 4, 2, 1, 4) RQ_CASE(3, 4, 2, 1, 4) RQ_CASE(3, 12, 2, 1, 4) RQ_CASE(2, 1, 2, 1, 4) RQ_CASE(4, 4, 2, 1, 4)
     RQ_CASE(3, 4, 2, 1, 8)
 #undef RQ_CASE
     return hipErrorInvalidValue;

@@ -342,8 +342,8 @@ static hipError_t rq_scanw_launch_t(const RqScanArgs& a, int grid, hipStream_t s
 // Variants (option "wide128" / "wide256"; queries per pass = 16 * waves * groups):
 //   0  128 queries: 8 waves x 1 group, reads 12 fragments ahead                    <- default for 128
 //   1  128 queries: 8 waves x 1 group, reads 4 ahead
-//   2  256 queries: 8 waves x 2 groups, reads 2 ahead (256 VGPRs, nothing spilled in the loop)  <- default for 256
-//   3  256 queries: 8 waves x 2 groups, reads 3 ahead
+//   2  256 queries: 8 waves x 2 groups, reads 2 ahead: 256 VGPRs; 7 values are spilled, all of them outside the streaming
+//      loop (prologue, and one reload in the rare record-flush branch) -- reading 3 or 4 ahead spills inside it   <- default for 256
 //   4  128 queries: as 1 with rq_scan.hip's compare/select epilogue (A/B of the selection forms)
 //   5  128 queries: 4 waves x 2 groups, one wave per SIMD (A/B: a lone wave cannot overlap its own VALU with its MFMAs)
 //   6  128 queries: as 0 with the selection of waves 4..7 staggered by half a tile;  7: as 0 with s_setprio 1 for waves 4..7
@@ -354,7 +354,7 @@ hipError_t rq_scan_wide_launch(const RqScanArgs& a, int variant, int queries, bo
 #define RQW_CASE(V, DD, OO, QQ, GG, ...) \
     if (variant == V && queries == 16 * QQ * GG) \
         return nt ? rq_scanw_launch_t<true, DD, OO, QQ, GG, ##__VA_ARGS__>(a, grid, stream) : rq_scanw_launch_t<false, DD, OO, QQ, GG, ##__VA_ARGS__>(a, grid, stream);
-    RQW_CASE(0, 12, 2, 8, 1, 1) RQW_CASE(1, 4, 2, 8, 1, 1) RQW_CASE(2, 2, 2, 8, 2, 1) RQW_CASE(3, 3, 2, 8, 2, 1)
+    RQW_CASE(0, 12, 2, 8, 1, 1) RQW_CASE(1, 4, 2, 8, 1, 1) RQW_CASE(2, 2, 2, 8, 2, 1)
     RQW_CASE(4, 4, 2, 8, 1, 0) RQW_CASE(5, 4, 1, 4, 2, 1)
     RQW_CASE(6, 12, 2, 8, 1, 1, 0, 2) RQW_CASE(7, 12, 2, 8, 1, 1, 0, 1)
     RQW_CASE(90, 4, 2, 8, 1, 0, 1) RQW_CASE(91, 4, 2, 8, 1, 0, 2) RQW_CASE(92, 4, 2, 8, 1, 0, 3)

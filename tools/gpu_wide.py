@@ -13,7 +13,7 @@ for lo in range(0, N, 125_000):
     idx.add_f16_device(x, n)
 modes = [("64-pass", dict(wide_batch=0)), ("128-pass r1 (8 waves)", dict(wide_batch=2))]
 modes += [(f"128-pass wide v{v}", dict(wide_batch=3, wide128=v)) for v in (0, 1, 4, 5, 6, 7)]
-modes += [(f"256-pass wide v{v}", dict(wide_batch=1, wide128=0, wide256=v)) for v in (2, 3)]
+modes += [(f"256-pass wide v{v}", dict(wide_batch=1, wide128=0, wide256=v)) for v in (2,)]
 if os.environ.get("RQ_WIDE_ABLATE"):
     modes += [(f"128-pass ablation v{v}", dict(wide_batch=3, wide128=v)) for v in (90, 91, 92)]
 only = os.environ.get("RQ_WIDE_ONLY")
