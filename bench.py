@@ -49,12 +49,13 @@ def main() -> None:
     ap.add_argument("--pipeline", type=int, default=2, help="deferred tails: 1 = on the library's internal stream, 2 = fused into the next scan launch")
     ap.add_argument("--workload", default="headline", choices=["headline", "config2", "config3", "config4"],
                     help="headline = BASELINE.json configs[1] (the metric); config2/3/4 = the other GPU configs at their shapes on ONE GPU "
-                         "(tools/config_workloads.py, synthetic stand-ins), one JSON line each")
+                         "(tests/config_workloads.py, synthetic stand-ins), one JSON line each")
     args = ap.parse_args()
     if args.workload != "headline":
         if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
             raise SystemExit("--workload config2/3/4 are single-GPU legs")
-        from tools import config_workloads as cw
+        sys.path.insert(0, os.path.join(ROOT, "tests"))          # the harness lives with the tests (it uses the oracle as its checker)
+        import config_workloads as cw
         r = {"config2": cw.run_config2, "config3": cw.run_config3, "config4": cw.run_config4}[args.workload]()
         metric = {"config2": ("queries/sec, 10M x 768 fp16 in 8 row shards on one GPU, batch-64, top-10", r.get("queries_per_s")),
                   "config3": ("text queries/sec end to end (NomicBert forward + search over 1M x 768), 256 per call", r.get("text_queries_per_s")),

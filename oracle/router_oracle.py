@@ -1,6 +1,6 @@
 """CPU restatement of the reference's RetrievalRouter forward pass -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
 
-Only tests/, bench.py legs and tools/ measurement scripts may import this module.
+Only tests/ (tests/config_workloads.py is what `bench.py --workload config4` runs) may import this module.
 
 The router is the CONSUMER of the hot path (out of scope, "must run unchanged on its outputs"):
 BASELINE.json configs[4] feeds GPU dense top-100 + CPU BM25 top-100 through it and compares Recall@10.  The reference's

@@ -14,7 +14,7 @@ from typing import Dict, List
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # repo root (this file lives in tests/)
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

@@ -1,10 +1,14 @@
-"""BASELINE.json configs[2], [3], [4] at their shapes on one MI355X (tools/config_workloads.py).  Wikipedia embeddings,
+"""BASELINE.json configs[2], [3], [4] at their shapes on one MI355X (tests/config_workloads.py).  Wikipedia embeddings,
 nomic-embed-text weights and NQ-dev-500 do not exist offline: the workloads are synthetic stand-ins of the same shape
 (the result dicts say so under "data") -- what is asserted is parity of the GPU path with the oracle, not retrieval
 quality on real data."""
 import pytest
 
-from tools import config_workloads as cw
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import config_workloads as cw  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 

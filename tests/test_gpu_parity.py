@@ -604,6 +604,27 @@ def test_nomic_bert_embedder_end_to_end_random_init():
         NomicBertEmbedder()          # no weights, no random_init: refuses, never downloads
 
 
+def test_nomic_bert_gpu_forward_matches_fp32_cpu_reference():
+    """the embedder forward on PyTorch-ROCm (fp16, cuda) against a plain PyTorch fp32 CPU forward of the SAME
+    weights and tokens (random init, 3 layers): per-text cosine >= 0.999 and the same nearest passage for every query.
+    (The real nomic-embed-text weights are absent offline: this pins the plumbing -- tokenisation, masking, mean pooling,
+    dtype handling -- not retrieval quality.)"""
+    import torch
+    from rag_uq_amd.embedders import NomicBertEmbedder
+    torch.manual_seed(0)
+    gpu = NomicBertEmbedder(random_init=True, num_layers=3, device="cuda:0", dtype="float16", batch_size=64)
+    cpu = NomicBertEmbedder(random_init=True, num_layers=3, device="cpu", dtype="float32", batch_size=64)
+    cpu.model.load_state_dict({k: v.detach().float().cpu() for k, v in gpu.model.state_dict().items()})
+    texts = [f"passage {i}: the quick brown fox number {i * 7919 % 1000} jumps over topic {i % 13}" for i in range(96)] + ["", "a", "x" * 700]
+    a, b = gpu.embed(texts), cpu.embed(texts)
+    assert a.shape == b.shape == (99, 768) and np.isfinite(a).all()
+    cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+    assert cos.min() >= 0.999, cos.min()
+    an, bn = a / np.linalg.norm(a, axis=1, keepdims=True), b / np.linalg.norm(b, axis=1, keepdims=True)
+    qa, qb = gpu.embed(texts[:10]), cpu.embed(texts[:10])
+    assert ((qa @ an[10:].T).argmax(1) == (qb @ bn[10:].T).argmax(1)).all()
+
+
 def test_three_million_rows_addressing_beyond_4gb():
     """4.6 GB shard: every byte offset past 2^32 is exercised (scan, re-score, read-back).  Planted copies of
     late rows must come back at rank 1 and one query is checked against the oracle outright."""
@@ -874,6 +895,13 @@ def test_multi_device_index_persistence_and_row_offset(tmp_path):
         assert len(back) == 5_003
         _check(back, x16, q, 12)
         back.close()
+    tiny = nat.NativeIndex(96, devices=[0, 0, 0])                 # fewer rows than device slots: one slot stays empty
+    tiny.add_f16(x16[:2]); tiny.add_f16(x16[2:3])
+    _check(tiny, x16[:3], q, 5)                                  # k > rows: -1 padding after the merge
+    empty = nat.NativeIndex(96, devices=[0, 0])
+    se, re_ = empty.search(q, 4)
+    assert (re_ == -1).all() and not se.any()
+    tiny.close(); empty.close()
     with pytest.raises(nat.RqError, match="multi-device"):
         m.search_device(8, 1, 1, 0, 8, 8, None, 8)          # (dummy non-null addresses: refused before anything is touched)
     assert m.timing()["queries"] == 9
