@@ -100,7 +100,7 @@ struct rq_index {
     unsigned long long* dbg_stamps = nullptr;   // development (rq_debug_stamps)
     uint64_t scan_seq = 0;         // scan launches seen while profile = 1 (every profile_stride-th one is timed)
     // options
-    int ring = 3, prefetch = 1, kstage = 2, wide_batch = 1, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, profile_stride = 1, scan_nostore = 0, fast_tail = 1, pipeline = 0, tail_stop = 0, poison_cand = 0, wide128 = 0, wide256 = 2;
+    int ring = 3, prefetch = 1, kstage = 2, wide_batch = 1, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, profile_stride = 1, scan_nostore = 0, fast_tail = 1, pipeline = 0, tail_stop = 0, poison_cand = 0, wide128 = 0, wide256 = 11;
     double eps = -1.0;
     std::map<hipStream_t, StreamCtx> ctx;
     hipStream_t own_stream = nullptr;
@@ -392,7 +392,7 @@ extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     const std::string s(name);
     if (s == "ring") { if (v < 2 || v > 6) return set_err(RQ_EINVAL, "ring must be 2..6"); idx->ring = (int)v; }
     else if (s == "wide_batch") { if (v < 0 || v > 3) return set_err(RQ_EINVAL, "wide_batch must be 0..3"); idx->wide_batch = (int)v; }
-    else if (s == "wide128") { if (v < 0 || v > 92) return set_err(RQ_EINVAL, "wide128: a 128-query variant of csrc/rq_scan_wide.hip"); idx->wide128 = (int)v; }
+    else if (s == "wide128") { if (v < 0 || v > 99) return set_err(RQ_EINVAL, "wide128: a 128-query variant of csrc/rq_scan_wide.hip"); idx->wide128 = (int)v; }
     else if (s == "wide256") { if (v < 0 || v > 92) return set_err(RQ_EINVAL, "wide256: a 256-query variant of csrc/rq_scan_wide.hip"); idx->wide256 = (int)v; }
     else if (s == "kstage") { if (v != 1 && v != 2) return set_err(RQ_EINVAL, "kstage must be 1 or 2"); idx->kstage = (int)v; }
     else if (s == "prefetch") { if (v != 1 && v != 4 && v != 6 && v != 12) return set_err(RQ_EINVAL, "prefetch must be 1, 4, 6 or 12"); idx->prefetch = (int)v; }

@@ -128,8 +128,24 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
         for (int s = 0; s < 24; ++s) asm volatile("" : "+v"(qf[g][s]));   // ordinary loads retired before the main loop
     }
 
+    // PRIO == 3: the fragment reads are asm (ds_read_b128 with immediate offsets from 8 per-lane base addresses) and every
+    // MFMA group waits with a COUNTED s_waitcnt lgkmcnt(D): exactly D younger fragment reads may still be in flight.  The
+    // compiler's own schedule drains the whole LDS queue (lgkmcnt(0)) every few fragments, which exposes the latency of the
+    // read it has just issued.  LDS operations return in order, so other LDS instructions (the compiler's: row scales,
+    // record staging, shuffles) between the asm reads can only make a counted wait stricter, never too lax.
+    unsigned abase[2][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        abase[0][m] = (unsigned)(size_t)(lds_ptr_w)rq_smem_w + (rbase0 ^ (unsigned)(m << 6));
+        abase[1][m] = abase[0][m] + 2 * STAGE_BYTES;
+    }
     auto frag = [&](int t, int s) -> rq_half8 {
         if (DBG == 2) { rq_half8 z; asm volatile("" : "=v"(z)); return z; }
+        if (PRIO == 3) {
+            rq_half8 v;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(abase[t >> 1][s & 3]), "n"((t & 1) * STAGE_BYTES + ((s & ~3) << 6)));
+            return v;
+        }
         return *(const rq_half8*)(rq_smem_w + t * STAGE_BYTES + (rbase0 ^ (unsigned)((s & 3) << 6)) + ((s & ~3) << 6));
     };
     auto flush = [&](int quad0, int count) {
@@ -193,6 +209,8 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
                     av[f % D] = frag(0, r - 96);
                 }
             }
+            rq_half8 curw = cur;
+            if (PRIO == 3) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(curw) : "n"(D));   // fragment f has landed; f+1 .. f+D may be in flight
             rq_float4 (&acc)[QG] = acc2[t & 1];
             if (s == 0) {
 #pragma unroll
@@ -200,10 +218,10 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
             }
             if (DBG == 3) {
 #pragma unroll
-                for (int g = 0; g < QG; ++g) asm volatile("" : "+v"(acc[g]) : "v"(cur), "v"(qf[g][s]));
+                for (int g = 0; g < QG; ++g) asm volatile("" : "+v"(acc[g]) : "v"(curw), "v"(qf[g][s]));
             } else {
 #pragma unroll
-            for (int g = 0; g < QG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur, qf[g][s], acc[g], 0, 0, 0);
+            for (int g = 0; g < QG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(curw, qf[g][s], acc[g], 0, 0, 0);
             }
             if (PRIO == 2 && EPI == 1 && DBG == 0) {
                 if (s == 11 && t >= 1) { if (late) select_tile(t - 1); }
@@ -340,15 +358,18 @@ static hipError_t rq_scanw_launch_t(const RqScanArgs& a, int grid, hipStream_t s
 }
 
 // Variants (option "wide128" / "wide256"; queries per pass = 16 * waves * groups):
-//   0  128 queries: 8 waves x 1 group, reads 12 fragments ahead                    <- default for 128
-//   1  128 queries: 8 waves x 1 group, reads 4 ahead
-//   2  256 queries: 8 waves x 2 groups, reads 2 ahead: 256 VGPRs; 7 values are spilled, all of them outside the streaming
-//      loop (prologue, and one reload in the rare record-flush branch) -- reading 3 or 4 ahead spills inside it   <- default for 256
+//   0  128 queries: 8 waves x 1 group, reads 12 fragments ahead, compiler-scheduled LDS waits          <- default for 128
+//   1  128 queries: as 0, reads 4 ahead
+//   8  128 queries: as 0 with asm fragment reads + counted lgkmcnt waits (within 1 % of 0)
+//  11  256 queries: 8 waves x 2 groups, reads 2 ahead, asm fragment reads + counted lgkmcnt waits: 256 VGPRs, nothing
+//      spilled (385-398 us per pass)                                                                   <- default for 256
+//   2  256 queries: as 11 with compiler-scheduled reads (7 values spilled outside the streaming loop; 400-415 us)
 //   4  128 queries: as 1 with rq_scan.hip's compare/select epilogue (A/B of the selection forms)
 //   5  128 queries: 4 waves x 2 groups, one wave per SIMD (A/B: a lone wave cannot overlap its own VALU with its MFMAs)
 //   6  128 queries: as 0 with the selection of waves 4..7 staggered by half a tile;  7: as 0 with s_setprio 1 for waves 4..7
 //      (A/B of the two-waves-per-SIMD levers of MI355X_MICROARCH.md: neither beats 0 once the accumulators alternate)
-//   90..92  timing experiments on variant 4's shape, results invalid: no epilogue / no LDS reads / no MFMAs
+//   90..95  timing experiments, results invalid: no selection / no LDS fragment reads / no MFMAs, on variant 4's (90-92)
+//      and variant 0's (93-95) shape
 hipError_t rq_scan_wide_launch(const RqScanArgs& a, int variant, int queries, bool nt, int grid, hipStream_t stream) {
     if (grid <= 0) return hipErrorInvalidValue;
 #define RQW_CASE(V, DD, OO, QQ, GG, ...) \
@@ -357,7 +378,9 @@ hipError_t rq_scan_wide_launch(const RqScanArgs& a, int variant, int queries, bo
     RQW_CASE(0, 12, 2, 8, 1, 1) RQW_CASE(1, 4, 2, 8, 1, 1) RQW_CASE(2, 2, 2, 8, 2, 1)
     RQW_CASE(4, 4, 2, 8, 1, 0) RQW_CASE(5, 4, 1, 4, 2, 1)
     RQW_CASE(6, 12, 2, 8, 1, 1, 0, 2) RQW_CASE(7, 12, 2, 8, 1, 1, 0, 1)
+    RQW_CASE(8, 12, 2, 8, 1, 1, 0, 3) RQW_CASE(11, 2, 2, 8, 2, 1, 0, 3)
     RQW_CASE(90, 4, 2, 8, 1, 0, 1) RQW_CASE(91, 4, 2, 8, 1, 0, 2) RQW_CASE(92, 4, 2, 8, 1, 0, 3)
+    RQW_CASE(93, 12, 2, 8, 1, 1, 1) RQW_CASE(94, 12, 2, 8, 1, 1, 2) RQW_CASE(95, 12, 2, 8, 1, 1, 3)
 #undef RQW_CASE
     return hipErrorInvalidValue;
 }

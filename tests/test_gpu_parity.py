@@ -176,9 +176,10 @@ def test_every_kernel_variant_is_exact(corpus100k, opts):
 
 
 @pytest.mark.parametrize("opts", [dict(wide_batch=1), dict(wide_batch=3), dict(wide_batch=2), dict(wide_batch=0),
-                                  # every variant built in csrc/rq_scan_wide.hip: 128-query passes 0 / 1 / 4 / 5, 256-query pass 2
+                                  # every variant built in csrc/rq_scan_wide.hip: 128-query passes 0 / 1 / 4 / 5 / 6 / 7 / 8, 256-query passes 11 / 2
                                   dict(wide_batch=3, wide128=1), dict(wide_batch=3, wide128=4), dict(wide_batch=3, wide128=5),
-                                  dict(wide_batch=3, wide128=6), dict(wide_batch=3, wide128=7),
+                                  dict(wide_batch=3, wide128=6), dict(wide_batch=3, wide128=7), dict(wide_batch=3, wide128=8),
+                                  dict(wide_batch=1, wide256=2),
                                   dict(wide_batch=1, nt=1), dict(wide_batch=1, cu_count=5)])
 def test_every_wide_pass_variant_is_exact(corpus100k, opts):
     """Calls with more than 64 queries are cut into passes of 256 / 128 / 64 queries (csrc/rq_api.hip run_pipeline).

@@ -12,10 +12,10 @@ for lo in range(0, N, 125_000):
     x = torch.nn.functional.normalize(torch.randn((n, 768), device=dev, generator=g), dim=1).half().contiguous()
     idx.add_f16_device(x, n)
 modes = [("64-pass", dict(wide_batch=0)), ("128-pass r1 (8 waves)", dict(wide_batch=2))]
-modes += [(f"128-pass wide v{v}", dict(wide_batch=3, wide128=v)) for v in (0, 1, 4, 5, 6, 7)]
-modes += [(f"256-pass wide v{v}", dict(wide_batch=1, wide128=0, wide256=v)) for v in (2,)]
+modes += [(f"128-pass wide v{v}", dict(wide_batch=3, wide128=v)) for v in (0, 1, 8, 4, 5, 6, 7)]
+modes += [(f"256-pass wide v{v}", dict(wide_batch=1, wide128=0, wide256=v)) for v in (11, 2)]
 if os.environ.get("RQ_WIDE_ABLATE"):
-    modes += [(f"128-pass ablation v{v}", dict(wide_batch=3, wide128=v)) for v in (90, 91, 92)]
+    modes += [(f"128-pass ablation v{v}", dict(wide_batch=3, wide128=v)) for v in (90, 91, 92, 93, 94, 95)]
 only = os.environ.get("RQ_WIDE_ONLY")
 for B in (128, 256, 512):
     q = torch.randn((B, 768), device=dev, generator=g)

@@ -18,6 +18,6 @@ o = (torch.empty((B, k), device=dev), torch.empty((B, k), device=dev, dtype=torc
 for spec in specs:
     for kv in spec.split(","):
         n_, v_ = kv.split("="); idx.set_option(n_, float(v_))
-    for i in range(5): idx.search_device(q, B, k, 0, o[0], o[1], None, o[2], 0)
+    for i in range(24): idx.search_device(q, B, k, 0, o[0], o[1], None, o[2], 0)
     torch.cuda.synchronize()
 print("done", flush=True)
