@@ -77,6 +77,34 @@ __host__ __device__ static inline float rq_code16_value(uint32_t c) {
 }
 
 #ifdef __HIPCC__
+// ---- selection with the row position inside the score (rq_scan_wide.hip, rq_scan.hip EPI = 1) ----------------------
+// A score is clamped to the finite range (an infinite score stays the largest, NaN becomes the smallest), its 6 low
+// mantissa bits are REPLACED by the row's position in the quad, and it is inserted into the lane's sorted triple
+// m1 >= m2 >= m3 with three VALU instructions: positions ride along, no data-dependent code.  Written as asm because the
+// compiler turns fmaxf / fmed3(a, b, +inf) on a value that went through integer bit operations into canonicalise + v_max;
+// the operands are never NaN here.  The perturbation (< 64 ulp, 7.6e-6 relative) is part of the scan's error bound.
+__device__ __forceinline__ float rq_pos_score(float acc_times_scale, uint32_t pos) {
+    const float sc = __builtin_amdgcn_fmed3f(acc_times_scale, -3.4028234664e38f, 3.4028234664e38f);
+    return __uint_as_float((__float_as_uint(sc) & 0xffffffc0u) | pos);
+}
+__device__ __forceinline__ void rq_insert3(float& m1, float& m2, float& m3, float x) {
+    float n3, n2, n1;
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(n3) : "v"(m2), "v"(m3), "v"(x));
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(n2) : "v"(m1), "v"(m2), "v"(x));
+    asm("v_max_f32 %0, %1, %2" : "=v"(n1) : "v"(m1), "v"(x));
+    m3 = n3; m2 = n2; m1 = n1;
+}
+// The 8-byte bin record from a merged triple whose values carry complete positions.  Every field is an UPPER bound of the
+// UNPERTURBED score: low bits all ones for a positive value, all zeros for a negative one, then rounded up to 26 / 16 bits.
+__device__ __forceinline__ uint2 rq_record_from_triple(float x1, float x2, float x3) {
+    const uint32_t b1 = __float_as_uint(x1), b2 = __float_as_uint(x2), b3 = __float_as_uint(x3);
+    const uint32_t f1 = (b1 & 0xffffffc0u) + ((int32_t)b1 >= 0 ? 64u : 0u);   // = rq_up26 of that bound
+    const uint32_t u2 = (int32_t)b2 >= 0 ? (b2 | 63u) : (b2 & 0xffffffc0u);
+    const uint32_t u3 = (int32_t)b3 >= 0 ? (b3 | 63u) : (b3 & 0xffffffc0u);
+    const uint32_t c2 = rq_code16(__uint_as_float(u2)), c3 = rq_code16(__uint_as_float(u3)), d = c2 - c3;   // c3 <= c2
+    return make_uint2(f1 | (b1 & 63u), (c2 << 16) | ((d < 1023u ? d : 1023u) << 6) | (b2 & 63u));
+}
+
 __device__ __forceinline__ double rq_wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

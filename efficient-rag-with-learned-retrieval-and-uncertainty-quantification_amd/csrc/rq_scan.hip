@@ -48,7 +48,9 @@ __device__ __forceinline__ void rq_wait_vmcnt() {
 // their MFMAs (1, 4, 6 or 12); OCC: waves per SIMD the register allocation must allow; KS: stages per
 // tile (2: a stage is 16 half rows = 12 KiB; 1: a stage is 16 whole rows = 24 KiB contiguous in HBM);
 // QW: waves per workgroup = 16-query groups scored per corpus pass (4: 64 queries, 8: 128 queries).
-template <int S, bool NT, int PF, int KS, int QW>
+// EPI: 1 = selection with the row position in the low mantissa bits of the score (rq_device.h rq_insert3: 6 VALU per
+//      score, no data-dependent code, no per-score row test -- the pad rows' row scale is NaN); 0 = compare / select form.
+template <int S, bool NT, int PF, int KS, int QW, int EPI = 0>
 __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, const int G) {
     static_assert(S >= 2 && S <= 8, "ring depth");
     static_assert(PF == 1 || PF == 4 || PF == 6 || PF == 12, "fragment prefetch group");
@@ -174,6 +176,10 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
             // tile epilogue: D[row = 4*kg + i][query = r16]
             const rq_float4 nv = *(const rq_float4*)(nrow + t * 64);
             const int64_t row0 = (int64_t)quad * RQ_QUAD_ROWS + t * RQ_TILE_ROWS + 4 * kg;
+            if (EPI == 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rq_insert3(m1, m2, m3, rq_pos_score(acc[i] * nv[i], (uint32_t)(t * 16 + i)));
+            } else
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float sc = acc[i] * nv[i];
@@ -188,6 +194,20 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
                 m1 = gt1 ? sc : m1;
             }
         }
+        if (EPI == 1) {
+            // positions become complete (row group of the lane); the four lanes that share the query insert each other's triples
+            const uint32_t kgb = (uint32_t)kg << 2;
+            m1 = __uint_as_float(__float_as_uint(m1) | kgb); m2 = __uint_as_float(__float_as_uint(m2) | kgb); m3 = __uint_as_float(__float_as_uint(m3) | kgb);
+#pragma unroll
+            for (int off = 16; off <= 32; off <<= 1) {
+                const float o1 = __shfl_xor(m1, off, 64), o2 = __shfl_xor(m2, off, 64), o3 = __shfl_xor(m3, off, 64);
+                rq_insert3(m1, m2, m3, o1);
+                rq_insert3(m1, m2, m3, o2);
+                rq_insert3(m1, m2, m3, o3);
+            }
+            asm("v_max_f32 %0, %1, %2" : "=v"(wmax) : "v"(wmax), "v"(m1));
+            if (kg == 0) stg[(16 * wave + r16) * SQ + (lq & (SQ - 1))] = rq_record_from_triple(m1, m2, m3);
+        } else {
         // merge the four lane groups that share this query (lanes r16, r16+16, r16+32, r16+48): all end up equal
         ap = (ap & 0xffffu) + (uint32_t)(4 * kg) * 0x0101u;
         // merge the sorted triples of the two lists (this lane's and the other lane's): both lanes compute the same
@@ -212,6 +232,7 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
             stg[(16 * wave + r16) * SQ + (lq & (SQ - 1))] =
                 make_uint2(rq_up26(m1) | (ap & 63u), (c2 << 16) | ((d < 1023u ? d : 1023u) << 6) | ((ap >> 8) & 63u));
         }
+        }
         if ((lq & (SQ - 1)) == SQ - 1 || lq == nloc - 1)
             flush(q_lo + (lq & ~(SQ - 1)), (lq & (SQ - 1)) + 1);
     }
@@ -226,9 +247,9 @@ static constexpr size_t rq_scan_lds_bytes(int S, int KS, int QW) {
     return (size_t)S * (24576 / KS) + 512 + (size_t)16 * QW * rq_stage_quads(QW) * 8;
 }
 
-template <int S, bool NT, int PF, int OCC, int KS, int QW>
+template <int S, bool NT, int PF, int OCC, int KS, int QW, int EPI>
 __global__ __launch_bounds__(64 * QW, OCC) void rq_scan_kernel(RqScanArgs a) {
-    rq_scan_body<S, NT, PF, KS, QW>(a, (int)blockIdx.x, (int)gridDim.x);
+    rq_scan_body<S, NT, PF, KS, QW, EPI>(a, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Fused launch: workgroups [0, scan_grid) scan the corpus for THIS batch, the others run the tail (threshold, fp64
@@ -237,12 +258,12 @@ __global__ __launch_bounds__(64 * QW, OCC) void rq_scan_kernel(RqScanArgs a) {
 // overlap each other.  Scan variant: ring of 3 half-row stages, prefetch 1 (36 KB ring + 16.5 KB of record staging =
 // 53 760 B of LDS, <= 168 VGPRs), so a CU holds 2 scan workgroups + 1 tail workgroup (3 x 53 760 B <= 160 KB; the
 // tail's 16 KB are carved from the ring).
-template <bool NT, int NV>
+template <bool NT, int NV, int EPI>
 __global__ __launch_bounds__(256, 3) void rq_scan_tail_kernel(RqScanArgs sa, RqTailArgs ta, int scan_grid, int tail_chunks) {
     unsigned long long t0 = 0;
     if (ta.dbg) t0 = wall_clock64();
     if ((int)blockIdx.x < scan_grid) {
-        rq_scan_body<3, NT, 1, 2, 4>(sa, (int)blockIdx.x, scan_grid);
+        rq_scan_body<3, NT, 1, 2, 4, EPI>(sa, (int)blockIdx.x, scan_grid);
     } else {
         const int t = (int)blockIdx.x - scan_grid;
         rq_tail_body<NV>(ta, t % tail_chunks, t / tail_chunks, tail_chunks, *reinterpret_cast<RqTailLds*>(rq_smem));
@@ -255,7 +276,7 @@ __global__ __launch_bounds__(256, 3) void rq_scan_tail_kernel(RqScanArgs sa, RqT
     }
 }
 
-template <int S, bool NT, int PF, int OCC, int KS, int QW>
+template <int S, bool NT, int PF, int OCC, int KS, int QW, int EPI>
 static hipError_t rq_scan_launch_t(const RqScanArgs& a, int grid, hipStream_t stream) {
     const size_t lds = rq_scan_lds_bytes(S, KS, QW);
     static unsigned long long attr_done = 0;   // one bit per device
@@ -263,23 +284,25 @@ static hipError_t rq_scan_launch_t(const RqScanArgs& a, int grid, hipStream_t st
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (!((attr_done >> (dev & 63)) & 1ull)) {
-        e = hipFuncSetAttribute((const void*)rq_scan_kernel<S, NT, PF, OCC, KS, QW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipFuncSetAttribute((const void*)rq_scan_kernel<S, NT, PF, OCC, KS, QW, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done |= 1ull << (dev & 63);
     }
-    hipLaunchKernelGGL((rq_scan_kernel<S, NT, PF, OCC, KS, QW>), dim3(grid), dim3(64 * QW), lds, stream, a);
+    hipLaunchKernelGGL((rq_scan_kernel<S, NT, PF, OCC, KS, QW, EPI>), dim3(grid), dim3(64 * QW), lds, stream, a);
     return hipGetLastError();
 }
 
-template <int S, int PF, int OCC, int KS, int QW>
+template <int S, int PF, int OCC, int KS, int QW, int EPI = 0>
 static hipError_t rq_scan_launch_r(const RqScanArgs& a, bool nt, int grid, hipStream_t stream) {
-    return nt ? rq_scan_launch_t<S, true, PF, OCC, KS, QW>(a, grid, stream) : rq_scan_launch_t<S, false, PF, OCC, KS, QW>(a, grid, stream);
+    return nt ? rq_scan_launch_t<S, true, PF, OCC, KS, QW, EPI>(a, grid, stream) : rq_scan_launch_t<S, false, PF, OCC, KS, QW, EPI>(a, grid, stream);
 }
 
 // (ring S, prefetch PF, stages-per-tile KS, waves QW) combinations that are built; anything else is an error.
 // qw = 4: 64 queries per pass; qw = 8: 128 queries per pass (one workgroup per CU, whole-row stages).
-hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int ks, int qw, bool nt, int grid, hipStream_t stream) {
+// epi = 1 (selection with positions inside the scores) exists for the default variant (ring 3, prefetch 1, half-row stages, 4 waves)
+hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int ks, int qw, bool nt, int grid, int epi, hipStream_t stream) {
     if (grid <= 0) return hipErrorInvalidValue;
+    if (epi && S == 3 && pf == 1 && ks == 2 && qw == 4) return rq_scan_launch_r<3, 1, 3, 2, 4, 1>(a, nt, grid, stream);
 #define RQ_CASE(SS, PP, OO, KK, QQ) if (S == SS && pf == PP && ks == KK && qw == QQ) return rq_scan_launch_r<SS, PP, OO, KK, QQ>(a, nt, grid, stream);
     RQ_CASE(3, 1, 3, 2, 4) RQ_CASE(4, 1, 3, 2, 4)
     RQ_CASE(4, 4, 2, 2, 4) RQ_CASE(6, 4, 2, 2, 4)
@@ -292,7 +315,7 @@ hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int ks, int qw, bo
 
 
 // ---- fused scan(batch i) + tail(batch i-1) -------------------------------------------------------------------
-template <bool NT, int NV>
+template <bool NT, int NV, int EPI>
 static hipError_t rq_scan_tail_launch_t(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, int scan_grid, hipStream_t stream) {
     constexpr size_t lds = rq_scan_lds_bytes(3, 2, 4);
     static_assert(sizeof(RqTailLds) <= lds, "tail LDS must fit in the scan's LDS");
@@ -304,16 +327,17 @@ static hipError_t rq_scan_tail_launch_t(const RqScanArgs& sa, const RqTailArgs& 
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (!((attr_done >> (dev & 63)) & 1ull)) {
-        e = hipFuncSetAttribute((const void*)rq_scan_tail_kernel<NT, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipFuncSetAttribute((const void*)rq_scan_tail_kernel<NT, NV, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done |= 1ull << (dev & 63);
     }
-    hipLaunchKernelGGL((rq_scan_tail_kernel<NT, NV>), dim3((unsigned)(scan_grid + chunks * tail_B)), dim3(256), lds, stream, sa, ta,
+    hipLaunchKernelGGL((rq_scan_tail_kernel<NT, NV, EPI>), dim3((unsigned)(scan_grid + chunks * tail_B)), dim3(256), lds, stream, sa, ta,
                        scan_grid, (int)chunks);
     return hipGetLastError();
 }
 
-hipError_t rq_scan_tail_launch(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, bool nt, int scan_grid, hipStream_t stream) {
+template <int EPI>
+static hipError_t rq_scan_tail_launch_e(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, bool nt, int scan_grid, hipStream_t stream) {
     if (scan_grid <= 0 || tail_B < 0) return hipErrorInvalidValue;   // tail_B = 0: development (the fused kernel without tail workgroups)
     if (ta.m < 1 || ta.m > RQ_FAST_MAX_M || ta.k < 1 || ta.k > RQ_FAST_MAX_K) return hipErrorInvalidValue;
     // Riding tails: as few workgroups as keep every CU's third slot busy once (~256): each tail workgroup costs the
@@ -321,10 +345,15 @@ hipError_t rq_scan_tail_launch(const RqScanArgs& sa, const RqTailArgs& ta, int t
     // 2048 bins 252.4 us).  The stand-alone launch (rq_tail_launch) prefers more, smaller ones: lower latency.
     const auto wgs = [&](int nv) { return ((ta.nbins + 512 * nv - 1) / (512 * nv)) * tail_B; };
     const int nv = wgs(1) <= 384 ? 1 : (wgs(4) <= 384 ? 4 : 8);
-    if (nt) return nv == 1 ? rq_scan_tail_launch_t<true, 1>(sa, ta, tail_B, scan_grid, stream)
-                 : nv == 4 ? rq_scan_tail_launch_t<true, 4>(sa, ta, tail_B, scan_grid, stream)
-                           : rq_scan_tail_launch_t<true, 8>(sa, ta, tail_B, scan_grid, stream);
-    return nv == 1 ? rq_scan_tail_launch_t<false, 1>(sa, ta, tail_B, scan_grid, stream)
-         : nv == 4 ? rq_scan_tail_launch_t<false, 4>(sa, ta, tail_B, scan_grid, stream)
-                   : rq_scan_tail_launch_t<false, 8>(sa, ta, tail_B, scan_grid, stream);
+    if (nt) return nv == 1 ? rq_scan_tail_launch_t<true, 1, EPI>(sa, ta, tail_B, scan_grid, stream)
+                 : nv == 4 ? rq_scan_tail_launch_t<true, 4, EPI>(sa, ta, tail_B, scan_grid, stream)
+                           : rq_scan_tail_launch_t<true, 8, EPI>(sa, ta, tail_B, scan_grid, stream);
+    return nv == 1 ? rq_scan_tail_launch_t<false, 1, EPI>(sa, ta, tail_B, scan_grid, stream)
+         : nv == 4 ? rq_scan_tail_launch_t<false, 4, EPI>(sa, ta, tail_B, scan_grid, stream)
+                   : rq_scan_tail_launch_t<false, 8, EPI>(sa, ta, tail_B, scan_grid, stream);
+}
+
+// epi: selection form of the scan workgroups (0 = compare / select, 1 = positions inside the scores)
+hipError_t rq_scan_tail_launch(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, bool nt, int scan_grid, int epi, hipStream_t stream) {
+    return epi ? rq_scan_tail_launch_e<1>(sa, ta, tail_B, nt, scan_grid, stream) : rq_scan_tail_launch_e<0>(sa, ta, tail_B, nt, scan_grid, stream);
 }

@@ -39,18 +39,6 @@ __host__ __device__ static constexpr int rqw_sq(int QW, int QG) { return QW * QG
 // EPI: 1 = the selection keeps the row position in the 6 low mantissa bits of the score (v_med3 inserts, 6 VALU per score),
 //      0 = rq_scan.hip's compare/select form (14 VALU per score).
 // DBG (timing experiments only, results invalid): 1 = no selection epilogue, 2 = no LDS fragment reads, 3 = no MFMAs
-__device__ __forceinline__ float rqw_med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
-// Insert x into the sorted triple m1 >= m2 >= m3: exactly three VALU instructions.  Written as asm because the compiler
-// turns fmaxf / fmed3(a, b, +inf) on a value that went through integer bit operations into canonicalise + v_max (two
-// instructions); x and the triple are never NaN here (scores are clamped to the finite range before their bits are touched).
-__device__ __forceinline__ void rqw_insert(float& m1, float& m2, float& m3, float x) {
-    float n3, n2, n1;
-    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(n3) : "v"(m2), "v"(m3), "v"(x));
-    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(n2) : "v"(m1), "v"(m2), "v"(x));
-    asm("v_max_f32 %0, %1, %2" : "=v"(n1) : "v"(m1), "v"(x));
-    m3 = n3; m2 = n2; m1 = n1;
-}
-
 template <bool NT, int D, int QW, int QG, int EPI, int DBG = 0, int PRIO = 0>
 __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, const int G) {
     static_assert(D >= 2 && D <= 12 && 24 % D == 0, "prefetch distance");
@@ -185,9 +173,7 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
             for (int g = 0; g < QG; ++g)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float sc = rqw_med3(acc2[t & 1][g][i] * nv[i], -3.4028234664e38f, 3.4028234664e38f);
-                    const float x = __uint_as_float((__float_as_uint(sc) & 0xffffffc0u) | (uint32_t)(t * 16 + i));
-                    rqw_insert(m1[g], m2[g], m3[g], x);
+                    rq_insert3(m1[g], m2[g], m3[g], rq_pos_score(acc2[t & 1][g][i] * nv[i], (uint32_t)(t * 16 + i)));
                 }
         };
 #pragma clang loop unroll(full)
@@ -244,9 +230,7 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
                 for (int g = 0; g < QG; ++g)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const float sc = rqw_med3(acc[g][i] * nv[i], -3.4028234664e38f, 3.4028234664e38f);
-                        const float x = __uint_as_float((__float_as_uint(sc) & 0xffffffc0u) | (uint32_t)(t * 16 + i));
-                        rqw_insert(m1[g], m2[g], m3[g], x);
+                        rq_insert3(m1[g], m2[g], m3[g], rq_pos_score(acc[g][i] * nv[i], (uint32_t)(t * 16 + i)));
                     }
             }
             if (s == 23 && DBG != 1 && EPI == 0) {
@@ -280,21 +264,12 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
 #pragma unroll
                 for (int off = 16; off <= 32; off <<= 1) {
                     const float o1 = __shfl_xor(x1, off, 64), o2 = __shfl_xor(x2, off, 64), o3 = __shfl_xor(x3, off, 64);
-                    rqw_insert(x1, x2, x3, o1);
-                    rqw_insert(x1, x2, x3, o2);
-                    rqw_insert(x1, x2, x3, o3);
+                    rq_insert3(x1, x2, x3, o1);
+                    rq_insert3(x1, x2, x3, o2);
+                    rq_insert3(x1, x2, x3, o3);
                 }
                 asm("v_max_f32 %0, %1, %2" : "=v"(wmax[g]) : "v"(wmax[g]), "v"(x1));
-                if (kg == 0) {
-                    // upper bounds of the UNPERTURBED scores: low bits all ones for a positive value, all zeros for a negative one
-                    const uint32_t b1 = __float_as_uint(x1), b2 = __float_as_uint(x2), b3 = __float_as_uint(x3);
-                    const uint32_t f1 = (b1 & 0xffffffc0u) + ((int32_t)b1 >= 0 ? 64u : 0u);   // = rq_up26 of that bound
-                    const uint32_t u2 = (int32_t)b2 >= 0 ? (b2 | 63u) : (b2 & 0xffffffc0u);
-                    const uint32_t u3 = (int32_t)b3 >= 0 ? (b3 | 63u) : (b3 & 0xffffffc0u);
-                    const uint32_t c2 = rq_code16(__uint_as_float(u2)), c3 = rq_code16(__uint_as_float(u3)), d = c2 - c3;   // c3 <= c2
-                    stg[(16 * (QG * wave + g) + r16) * SQ + (lq & (SQ - 1))] =
-                        make_uint2(f1 | (b1 & 63u), (c2 << 16) | ((d < 1023u ? d : 1023u) << 6) | (b2 & 63u));
-                }
+                if (kg == 0) stg[(16 * (QG * wave + g) + r16) * SQ + (lq & (SQ - 1))] = rq_record_from_triple(x1, x2, x3);
             }
         } else
 #pragma unroll

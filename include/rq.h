@@ -118,6 +118,7 @@ int rq_merge_keys_device(const uint64_t* d_keys_in, int n_per_query, int B, int 
  * "prefetch" (LDS fragments read ahead of their MFMAs: 1, 4, 6, 12), "fast_tail" (0 = generic sorted tail),
  * "pipeline" (see rq_search_flush_device), "wide_batch" (calls of more than 64 queries: 0 = passes of 64 only, 1 = passes of
  * 256 / 128 / 64, 3 = 128 / 64, 2 = round 1's 8-wave 128-query pass), "wide128" / "wide256" (variant of csrc/rq_scan_wide.hip),
+ * "epi" (selection form of the 64-query scan: 1 = row positions inside the scores, 0 = compare / select),
  * "poison_cand" (test hook: candidate lists are filled with 0xff..ff keys before every tail).
  * Read-only: "max_row_norm", "max_sub_rel" / "max_sub_abs" (largest share of a stored row that sits in fp16-subnormal elements,
  * which the matrix cores flush), "eps_cosine" / "eps_ip" (the certificate's bound including that term). */

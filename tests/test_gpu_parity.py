@@ -158,6 +158,7 @@ def test_clustered_near_ties():
 
 
 @pytest.mark.parametrize("opts", [dict(fast_tail=0), dict(fast_tail=0, slack_bins=0), dict(pipeline=1), dict(pipeline=2), dict(wide_batch=0),
+                                  dict(epi=0), dict(epi=0, pipeline=2), dict(epi=0, pipeline=1),
                                   dict(wg_per_cu=1), dict(wg_per_cu=3), dict(slack_bins=0),
                                   # every scan instantiation built in csrc/rq_scan.hip: (kstage, ring, prefetch)
                                   dict(kstage=1, ring=2, prefetch=1), dict(kstage=1, ring=2, prefetch=4), dict(kstage=1, ring=3, prefetch=4),
