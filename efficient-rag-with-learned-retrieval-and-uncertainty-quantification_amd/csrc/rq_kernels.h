@@ -98,7 +98,7 @@ struct RqTailArgs {
     int stop_after;                                // development: 0 = full kernel, 1..4 = return after phase A..D
 };
 // workgroups [0, scan_grid) run the scan `sa`, the rest the tail `ta` of an EARLIER batch 
-hipError_t rq_scan_tail_launch(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, bool nt, int scan_grid, int epi, hipStream_t stream);
+hipError_t rq_scan_tail_launch(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, bool nt, int scan_grid, int epi, bool tail_first, hipStream_t stream);
 hipError_t rq_tail_launch(const RqTailArgs& a, int B, hipStream_t stream);
 // chunk size rule shared by both launchers: 512-bin chunks while that keeps the grid around a thousand workgroups
 // (enough to spread the hits, few enough to be one dispatch round), else 2048-bin chunks

@@ -262,11 +262,17 @@ template <bool NT, int NV, int EPI>
 __global__ __launch_bounds__(256, 3) void rq_scan_tail_kernel(RqScanArgs sa, RqTailArgs ta, int scan_grid, int tail_chunks) {
     unsigned long long t0 = 0;
     if (ta.dbg) t0 = wall_clock64();
-    if ((int)blockIdx.x < scan_grid) {
-        rq_scan_body<3, NT, 1, 2, 4, EPI>(sa, (int)blockIdx.x, scan_grid);
+    // tail_chunks < 0: the tail workgroups take the FIRST block ids (dispatched before the scan workgroups), else the last
+    const int ntail = (int)gridDim.x - scan_grid;
+    const bool tail_first = tail_chunks < 0;
+    const int tc = tail_first ? -tail_chunks : tail_chunks;
+    const int bid = (int)blockIdx.x;
+    const int sb = tail_first ? bid - ntail : bid;          // scan workgroup index, valid in [0, scan_grid)
+    if (sb >= 0 && sb < scan_grid) {
+        rq_scan_body<3, NT, 1, 2, 4, EPI>(sa, sb, scan_grid);
     } else {
-        const int t = (int)blockIdx.x - scan_grid;
-        rq_tail_body<NV>(ta, t % tail_chunks, t / tail_chunks, tail_chunks, *reinterpret_cast<RqTailLds*>(rq_smem));
+        const int t = tail_first ? bid : bid - scan_grid;
+        rq_tail_body<NV>(ta, t % tc, t / tc, tc, *reinterpret_cast<RqTailLds*>(rq_smem));
     }
     if (ta.dbg && threadIdx.x == 0) {
         ta.dbg[4 * blockIdx.x] = t0; ta.dbg[4 * blockIdx.x + 1] = wall_clock64();
@@ -316,7 +322,7 @@ hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int ks, int qw, bo
 
 // ---- fused scan(batch i) + tail(batch i-1) -------------------------------------------------------------------
 template <bool NT, int NV, int EPI>
-static hipError_t rq_scan_tail_launch_t(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, int scan_grid, hipStream_t stream) {
+static hipError_t rq_scan_tail_launch_t(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, int scan_grid, bool tail_first, hipStream_t stream) {
     constexpr size_t lds = rq_scan_lds_bytes(3, 2, 4);
     static_assert(sizeof(RqTailLds) <= lds, "tail LDS must fit in the scan's LDS");
     static_assert(3 * lds <= 160 * 1024, "2 scan workgroups + 1 tail workgroup per CU");
@@ -332,12 +338,12 @@ static hipError_t rq_scan_tail_launch_t(const RqScanArgs& sa, const RqTailArgs& 
         attr_done |= 1ull << (dev & 63);
     }
     hipLaunchKernelGGL((rq_scan_tail_kernel<NT, NV, EPI>), dim3((unsigned)(scan_grid + chunks * tail_B)), dim3(256), lds, stream, sa, ta,
-                       scan_grid, (int)chunks);
+                       scan_grid, tail_first ? -(int)chunks : (int)chunks);
     return hipGetLastError();
 }
 
 template <int EPI>
-static hipError_t rq_scan_tail_launch_e(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, bool nt, int scan_grid, hipStream_t stream) {
+static hipError_t rq_scan_tail_launch_e(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, bool nt, int scan_grid, bool tail_first, hipStream_t stream) {
     if (scan_grid <= 0 || tail_B < 0) return hipErrorInvalidValue;   // tail_B = 0: development (the fused kernel without tail workgroups)
     if (ta.m < 1 || ta.m > RQ_FAST_MAX_M || ta.k < 1 || ta.k > RQ_FAST_MAX_K) return hipErrorInvalidValue;
     // Riding tails: as few workgroups as keep every CU's third slot busy once (~256): each tail workgroup costs the
@@ -345,15 +351,15 @@ static hipError_t rq_scan_tail_launch_e(const RqScanArgs& sa, const RqTailArgs& 
     // 2048 bins 252.4 us).  The stand-alone launch (rq_tail_launch) prefers more, smaller ones: lower latency.
     const auto wgs = [&](int nv) { return ((ta.nbins + 512 * nv - 1) / (512 * nv)) * tail_B; };
     const int nv = wgs(1) <= 384 ? 1 : (wgs(4) <= 384 ? 4 : 8);
-    if (nt) return nv == 1 ? rq_scan_tail_launch_t<true, 1, EPI>(sa, ta, tail_B, scan_grid, stream)
-                 : nv == 4 ? rq_scan_tail_launch_t<true, 4, EPI>(sa, ta, tail_B, scan_grid, stream)
-                           : rq_scan_tail_launch_t<true, 8, EPI>(sa, ta, tail_B, scan_grid, stream);
-    return nv == 1 ? rq_scan_tail_launch_t<false, 1, EPI>(sa, ta, tail_B, scan_grid, stream)
-         : nv == 4 ? rq_scan_tail_launch_t<false, 4, EPI>(sa, ta, tail_B, scan_grid, stream)
-                   : rq_scan_tail_launch_t<false, 8, EPI>(sa, ta, tail_B, scan_grid, stream);
+    if (nt) return nv == 1 ? rq_scan_tail_launch_t<true, 1, EPI>(sa, ta, tail_B, scan_grid, tail_first, stream)
+                 : nv == 4 ? rq_scan_tail_launch_t<true, 4, EPI>(sa, ta, tail_B, scan_grid, tail_first, stream)
+                           : rq_scan_tail_launch_t<true, 8, EPI>(sa, ta, tail_B, scan_grid, tail_first, stream);
+    return nv == 1 ? rq_scan_tail_launch_t<false, 1, EPI>(sa, ta, tail_B, scan_grid, tail_first, stream)
+         : nv == 4 ? rq_scan_tail_launch_t<false, 4, EPI>(sa, ta, tail_B, scan_grid, tail_first, stream)
+                   : rq_scan_tail_launch_t<false, 8, EPI>(sa, ta, tail_B, scan_grid, tail_first, stream);
 }
 
 // epi: selection form of the scan workgroups (0 = compare / select, 1 = positions inside the scores)
-hipError_t rq_scan_tail_launch(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, bool nt, int scan_grid, int epi, hipStream_t stream) {
-    return epi ? rq_scan_tail_launch_e<1>(sa, ta, tail_B, nt, scan_grid, stream) : rq_scan_tail_launch_e<0>(sa, ta, tail_B, nt, scan_grid, stream);
+hipError_t rq_scan_tail_launch(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, bool nt, int scan_grid, int epi, bool tail_first, hipStream_t stream) {
+    return epi ? rq_scan_tail_launch_e<1>(sa, ta, tail_B, nt, scan_grid, tail_first, stream) : rq_scan_tail_launch_e<0>(sa, ta, tail_B, nt, scan_grid, tail_first, stream);
 }

@@ -1,10 +1,13 @@
-"""A/B of the fused scan + tail launch's selection form (option fused_epi: 0 = compare / select, 1 = row position inside the
-score, v_med3 inserts), interleaved in ONE process on one box: us per 64-query batch over 1M rows, one stream, pipeline 2."""
+"""A/B of an option of the fused scan + tail launch, interleaved in ONE process on one box: us per 64-query batch over 1M
+rows, one stream, pipeline 2.   usage: python tools/gpu_ab_epi.py [option=epi]
+  epi        selection form: 0 = compare / select, 1 = row position inside the score (v_med3 inserts)
+  tail_first 1 = the tail workgroups take the first block ids of the launch"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 import rag_uq_amd
 from rag_uq_amd import _native as nat
+OPT = sys.argv[1] if len(sys.argv) > 1 else "epi"
 dev = torch.device("cuda:0"); N = 1_000_000; B = 64; k = 10
 idx = nat.NativeIndex(768, 0); idx.reserve(N)
 for c in range(8):
@@ -20,7 +23,7 @@ ref = None
 res = {0: [], 1: []}
 for rnd in range(7):
     for epi in (0, 1):
-        idx.set_option("fused_epi", epi)
+        idx.set_option(OPT, epi)
         idx.set_option("profile", 1); idx.set_option("profile_stride", 4); idx.reset_timing()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for i in range(240):
@@ -33,7 +36,7 @@ for rnd in range(7):
         bad = int(sum(int(o[2].sum()) for o in outs))
         if ref is None: ref = rows
         if rnd: res[epi].append((dt * 1e6, t["scan_ms"] * 1e3 / max(t["scan_launches"], 1)))
-        print(f"round {rnd} fused_epi={epi}: {dt*1e6:7.1f} us/batch  scan launch {t['scan_ms']*1e3/max(t['scan_launches'],1):6.1f} us  same_rows={bool(np.array_equal(rows, ref))} uncertified={bad}", flush=True)
+        print(f"round {rnd} {OPT}={epi}: {dt*1e6:7.1f} us/batch  scan launch {t['scan_ms']*1e3/max(t['scan_launches'],1):6.1f} us  same_rows={bool(np.array_equal(rows, ref))} uncertified={bad}", flush=True)
 for epi in (0, 1):
     a = np.array(res[epi])
-    print(f"fused_epi={epi}: mean {a[:,0].mean():.1f} us/batch (min {a[:,0].min():.1f}), scan launch mean {a[:,1].mean():.1f} us")
+    print(f"{OPT}={epi}: mean {a[:,0].mean():.1f} us/batch (min {a[:,0].min():.1f}), scan launch mean {a[:,1].mean():.1f} us")
