@@ -231,6 +231,8 @@ def main() -> None:
     for i in range(args.warmup):
         step(i)
     flush()
+    finish()        # the end-of-run sequence once before the timed region: the first numpy reduction / nonzero of a process cost
+    fixup_all()     # ~90 us of lazy initialisation on the host (measured), which a 20-step run would otherwise carry
     sync_all()
     # HIP events around every scan launch of the timed region (the roofline's live figure).  They cost ~5 us per
     # step, which is 2 % at one GPU and 10 % of a 125k-row shard's step: at N > 1 the timed region runs without
