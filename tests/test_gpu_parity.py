@@ -695,7 +695,7 @@ def test_long_structured_sweep():
     for case in range(ncases):
         big = case < int(os.environ.get("RQ_LONG_SWEEP_BIG", "0"))       # the first few cases at the headline size
         n = 1_000_000 if big else int(rng.choice([9_000, 20_011, 65_536, 100_003, 180_000]))
-        B = int(rng.choice([1, 7, 64, 64, 100]))
+        B = int(rng.choice([1, 7, 64, 64, 100, 130, 260]))
         k = int(rng.choice([1, 10, 10, 50, 100, 128]))
         metric = int(rng.integers(0, 2))
         kind = str(rng.choice(["gauss", "docs", "clusters", "dups"]))
@@ -728,6 +728,8 @@ def test_long_structured_sweep():
         idx = nat.NativeIndex(768, 0)
         idx.add_f16(x16)
         mode = int(rng.choice([0, 1, 2]))
+        idx.set_option("epi", int(rng.integers(0, 2)))
+        idx.set_option("wide_batch", int(rng.choice([1, 1, 3, 0])))
         try:
             if mode == 0:
                 _check(idx, x16, q, k, metric)
