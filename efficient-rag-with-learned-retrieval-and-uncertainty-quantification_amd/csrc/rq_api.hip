@@ -100,7 +100,7 @@ struct rq_index {
     unsigned long long* dbg_stamps = nullptr;   // development (rq_debug_stamps)
     uint64_t scan_seq = 0;         // scan launches seen while profile = 1 (every profile_stride-th one is timed)
     // options
-    int ring = 3, prefetch = 1, kstage = 2, wide_batch = 1, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, profile_stride = 1, scan_nostore = 0, fast_tail = 1, pipeline = 0, tail_stop = 0, poison_cand = 0, wide128 = 0, wide256 = 11, epi = 1, tail_first = 0;
+    int ring = 3, prefetch = 1, kstage = 2, wide_batch = 1, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, profile_stride = 1, scan_nostore = 0, fast_tail = 1, pipeline = 0, tail_stop = 0, poison_cand = 0, wide128 = 0, wide256 = 11, epi = 1, tail_first = 0, profile_legacy = 0;
     double eps = -1.0;
     std::map<hipStream_t, StreamCtx> ctx;
     hipStream_t own_stream = nullptr;
@@ -408,6 +408,7 @@ extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     else if (s == "pipeline") { if (v != 0 && v != 1 && v != 2) return set_err(RQ_EINVAL, "pipeline must be 0, 1 or 2"); if (int r = flush_all(idx)) return r; idx->pipeline = (int)v; }
     else if (s == "tail_stop") idx->tail_stop = (int)v;
     else if (s == "epi" || s == "fused_epi") idx->epi = (int)v != 0;   // selection form of the 64-query scan (default variant and fused launch): 1 = positions inside the scores, 0 = compare / select
+    else if (s == "profile_legacy") idx->profile_legacy = (int)v != 0;   // time scans with hipEventRecord around the launch (round 1) instead of dispatch-attached events
     else if (s == "tail_first") idx->tail_first = (int)v != 0;   // fused launch: tail workgroups take the first block ids
     else if (s == "poison_cand") idx->poison_cand = (int)v;   // test hook: candidate lists are filled with 0xff..ff keys before every tail
     else return set_err(RQ_EINVAL, "unknown option '%s'", name);
@@ -662,30 +663,32 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             a.wgmax = w.wgmax + (size_t)q0 * RQ_WGMAX_STRIDE;
             a.wgmax_stride = RQ_WGMAX_STRIDE;
             const bool prof = idx->profile == 1 && idx->ev_used < 16384 && (idx->scan_seq++ % (uint64_t)idx->profile_stride) == 0;
-            if (prof) {
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (prof) {   // the event pair rides on the scan dispatch itself (kernel start / end time stamps, no barrier packets)
                 if (idx->ev_used == idx->events.size()) {
-                    hipEvent_t e0, e1;
-                    HIPCHK(hipEventCreate(&e0));
-                    HIPCHK(hipEventCreate(&e1));
-                    idx->events.push_back({e0, e1});
+                    hipEvent_t n0, n1;
+                    HIPCHK(hipEventCreate(&n0));
+                    HIPCHK(hipEventCreate(&n1));
+                    idx->events.push_back({n0, n1});
                 }
-                HIPCHK(hipEventRecord(idx->events[idx->ev_used].first, s));
+                e0 = idx->events[idx->ev_used].first; e1 = idx->events[idx->ev_used].second;
+                if (idx->profile_legacy) { HIPCHK(hipEventRecord(e0, s)); e0 = e1 = nullptr; }   // A/B: hipEventRecord around the launch
             }
             if (fused && cx.fused_pending) {
                 cx.fused_pending = false;
                 if (int r = poison_cand(idx, cx.fused_tail, cx.fused_B, s)) return r;
                 if (idx->tail_stop == 9) {   // development: fused kernel without its tail workgroups, tail launched after it
-                    HIPCHK(rq_scan_tail_launch(a, cx.fused_tail, 0, nt, grid, idx->epi, idx->tail_first != 0, s));
+                    HIPCHK(rq_scan_tail_launch(a, cx.fused_tail, 0, nt, grid, idx->epi, idx->tail_first != 0, s, e0, e1));
                     RqTailArgs t9 = cx.fused_tail; t9.stop_after = 0;
                     HIPCHK(rq_tail_launch(t9, cx.fused_B, s));
                 } else
-                HIPCHK(rq_scan_tail_launch(a, cx.fused_tail, cx.fused_B, nt, grid, idx->epi, idx->tail_first != 0, s));
-            } else if (fused) HIPCHK(rq_scan_launch(a, 3, 1, 2, 4, nt, grid, idx->epi, s));
-            else if (qb == 256) HIPCHK(rq_scan_wide_launch(a, idx->wide256, 256, nt, grid, s));
-            else if (qb == 128 && idx->wide_batch == 2) HIPCHK(rq_scan_launch(a, 3, 4, 1, 8, nt, grid, 0, s));   // round 1's 8-wave pass
-            else if (qb == 128) HIPCHK(rq_scan_wide_launch(a, idx->wide128, 128, nt, grid, s));
-            else HIPCHK(rq_scan_launch(a, idx->ring, idx->prefetch, idx->kstage, 4, nt, grid, idx->epi, s));
-            if (prof) { HIPCHK(hipEventRecord(idx->events[idx->ev_used].second, s)); idx->ev_used++; }
+                HIPCHK(rq_scan_tail_launch(a, cx.fused_tail, cx.fused_B, nt, grid, idx->epi, idx->tail_first != 0, s, e0, e1));
+            } else if (fused) HIPCHK(rq_scan_launch(a, 3, 1, 2, 4, nt, grid, idx->epi, s, e0, e1));
+            else if (qb == 256) HIPCHK(rq_scan_wide_launch(a, idx->wide256, 256, nt, grid, s, e0, e1));
+            else if (qb == 128 && idx->wide_batch == 2) HIPCHK(rq_scan_launch(a, 3, 4, 1, 8, nt, grid, 0, s, e0, e1));   // round 1's 8-wave pass
+            else if (qb == 128) HIPCHK(rq_scan_wide_launch(a, idx->wide128, 128, nt, grid, s, e0, e1));
+            else HIPCHK(rq_scan_launch(a, idx->ring, idx->prefetch, idx->kstage, 4, nt, grid, idx->epi, s, e0, e1));
+            if (prof) { if (idx->profile_legacy) HIPCHK(hipEventRecord(idx->events[idx->ev_used].second, s)); idx->ev_used++; }
         }
         if (fast) {
             hipStream_t ts = s;

@@ -17,12 +17,16 @@ struct RqScanArgs {
 };
 #define RQ_WGMAX_STRIDE 1024   // scan grids never exceed this many workgroups
 
-hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int ks, int qw, bool nt, int grid, int epi, hipStream_t stream);
+// e0 / e1 (all scan launchers): optional events attached to the dispatch itself (hipExtLaunchKernel): the kernel's own start / end
+// time stamps, no extra barrier packets on the stream
+hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int ks, int qw, bool nt, int grid, int epi, hipStream_t stream,
+                          hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 
 // Passes of 128 / 256 queries (rq_scan_wide.hip): one 512-thread workgroup per CU, LDS reads running ahead of the MFMAs
 // across stage boundaries, v_med3 selection.  Returns hipErrorInvalidValue for a variant that is not built or does not
 // score `queries` queries per pass.
-hipError_t rq_scan_wide_launch(const RqScanArgs& a, int variant, int queries, bool nt, int grid, hipStream_t stream);
+hipError_t rq_scan_wide_launch(const RqScanArgs& a, int variant, int queries, bool nt, int grid, hipStream_t stream,
+                               hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 
 // Row statistics at add time: row_norm64[i] = sqrt(sum x^2) in fp64; stats[3] (device, running maxima as double bits):
 // largest norm, largest relative and absolute mass of fp16-subnormal elements in a row (see rq_select.hip).
@@ -98,7 +102,8 @@ struct RqTailArgs {
     int stop_after;                                // development: 0 = full kernel, 1..4 = return after phase A..D
 };
 // workgroups [0, scan_grid) run the scan `sa`, the rest the tail `ta` of an EARLIER batch 
-hipError_t rq_scan_tail_launch(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, bool nt, int scan_grid, int epi, bool tail_first, hipStream_t stream);
+hipError_t rq_scan_tail_launch(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, bool nt, int scan_grid, int epi, bool tail_first, hipStream_t stream,
+                               hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 hipError_t rq_tail_launch(const RqTailArgs& a, int B, hipStream_t stream);
 // chunk size rule shared by both launchers: 512-bin chunks while that keeps the grid around a thousand workgroups
 // (enough to spread the hits, few enough to be one dispatch round), else 2048-bin chunks

@@ -25,6 +25,8 @@
 //     wgmax[query][workgroup].  Writes are what the kernel is sensitive to: with a record per 16 rows (65 MB per
 //     launch, 16-byte pieces) the stores cost 62 of 289 us (measured by switching them off); a workgroup therefore
 //     owns a CONTIGUOUS range of quads and parks its records in LDS until the range is done (see `flush`).
+#include <hip/hip_ext.h>
+
 #include "rq_device.h"
 #include "rq_kernels.h"
 #include "rq_tail_body.h"
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(256, 3) void rq_scan_tail_kernel(RqScanArgs sa, RqT
 }
 
 template <int S, bool NT, int PF, int OCC, int KS, int QW, int EPI>
-static hipError_t rq_scan_launch_t(const RqScanArgs& a, int grid, hipStream_t stream) {
+static hipError_t rq_scan_launch_t(const RqScanArgs& a, int grid, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
     const size_t lds = rq_scan_lds_bytes(S, KS, QW);
     static unsigned long long attr_done = 0;   // one bit per device
     int dev = 0;
@@ -294,22 +296,25 @@ static hipError_t rq_scan_launch_t(const RqScanArgs& a, int grid, hipStream_t st
         if (e != hipSuccess) return e;
         attr_done |= 1ull << (dev & 63);
     }
-    hipLaunchKernelGGL((rq_scan_kernel<S, NT, PF, OCC, KS, QW, EPI>), dim3(grid), dim3(64 * QW), lds, stream, a);
+    // e0 / e1: events attached to the dispatch itself (hipExtLaunchKernel): they read the kernel's own start and end
+    // time stamps and cost no extra barrier packets (hipEventRecord around a launch costs ~5 us on each side)
+    if (e0 && e1) hipExtLaunchKernelGGL((rq_scan_kernel<S, NT, PF, OCC, KS, QW, EPI>), dim3(grid), dim3(64 * QW), (uint32_t)lds, stream, e0, e1, 0, a);
+    else hipLaunchKernelGGL((rq_scan_kernel<S, NT, PF, OCC, KS, QW, EPI>), dim3(grid), dim3(64 * QW), lds, stream, a);
     return hipGetLastError();
 }
 
 template <int S, int PF, int OCC, int KS, int QW, int EPI = 0>
-static hipError_t rq_scan_launch_r(const RqScanArgs& a, bool nt, int grid, hipStream_t stream) {
-    return nt ? rq_scan_launch_t<S, true, PF, OCC, KS, QW, EPI>(a, grid, stream) : rq_scan_launch_t<S, false, PF, OCC, KS, QW, EPI>(a, grid, stream);
+static hipError_t rq_scan_launch_r(const RqScanArgs& a, bool nt, int grid, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
+    return nt ? rq_scan_launch_t<S, true, PF, OCC, KS, QW, EPI>(a, grid, stream, e0, e1) : rq_scan_launch_t<S, false, PF, OCC, KS, QW, EPI>(a, grid, stream, e0, e1);
 }
 
 // (ring S, prefetch PF, stages-per-tile KS, waves QW) combinations that are built; anything else is an error.
 // qw = 4: 64 queries per pass; qw = 8: 128 queries per pass (one workgroup per CU, whole-row stages).
 // epi = 1 (selection with positions inside the scores) exists for the default variant (ring 3, prefetch 1, half-row stages, 4 waves)
-hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int ks, int qw, bool nt, int grid, int epi, hipStream_t stream) {
+hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int ks, int qw, bool nt, int grid, int epi, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
     if (grid <= 0) return hipErrorInvalidValue;
-    if (epi && S == 3 && pf == 1 && ks == 2 && qw == 4) return rq_scan_launch_r<3, 1, 3, 2, 4, 1>(a, nt, grid, stream);
-#define RQ_CASE(SS, PP, OO, KK, QQ) if (S == SS && pf == PP && ks == KK && qw == QQ) return rq_scan_launch_r<SS, PP, OO, KK, QQ>(a, nt, grid, stream);
+    if (epi && S == 3 && pf == 1 && ks == 2 && qw == 4) return rq_scan_launch_r<3, 1, 3, 2, 4, 1>(a, nt, grid, stream, e0, e1);
+#define RQ_CASE(SS, PP, OO, KK, QQ) if (S == SS && pf == PP && ks == KK && qw == QQ) return rq_scan_launch_r<SS, PP, OO, KK, QQ>(a, nt, grid, stream, e0, e1);
     RQ_CASE(3, 1, 3, 2, 4) RQ_CASE(4, 1, 3, 2, 4)
     RQ_CASE(4, 4, 2, 2, 4) RQ_CASE(6, 4, 2, 2, 4)
     RQ_CASE(5, 6, 2, 2, 4) RQ_CASE(6, 12, 2, 2, 4)
@@ -322,7 +327,8 @@ hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int ks, int qw, bo
 
 // ---- fused scan(batch i) + tail(batch i-1) -------------------------------------------------------------------
 template <bool NT, int NV, int EPI>
-static hipError_t rq_scan_tail_launch_t(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, int scan_grid, bool tail_first, hipStream_t stream) {
+static hipError_t rq_scan_tail_launch_t(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, int scan_grid, bool tail_first, hipStream_t stream,
+                                        hipEvent_t e0, hipEvent_t e1) {
     constexpr size_t lds = rq_scan_lds_bytes(3, 2, 4);
     static_assert(sizeof(RqTailLds) <= lds, "tail LDS must fit in the scan's LDS");
     static_assert(3 * lds <= 160 * 1024, "2 scan workgroups + 1 tail workgroup per CU");
@@ -337,13 +343,16 @@ static hipError_t rq_scan_tail_launch_t(const RqScanArgs& sa, const RqTailArgs& 
         if (e != hipSuccess) return e;
         attr_done |= 1ull << (dev & 63);
     }
-    hipLaunchKernelGGL((rq_scan_tail_kernel<NT, NV, EPI>), dim3((unsigned)(scan_grid + chunks * tail_B)), dim3(256), lds, stream, sa, ta,
-                       scan_grid, tail_first ? -(int)chunks : (int)chunks);
+    const int tc = tail_first ? -(int)chunks : (int)chunks;
+    if (e0 && e1) hipExtLaunchKernelGGL((rq_scan_tail_kernel<NT, NV, EPI>), dim3((unsigned)(scan_grid + chunks * tail_B)), dim3(256), (uint32_t)lds, stream, e0, e1, 0,
+                                        sa, ta, scan_grid, tc);
+    else hipLaunchKernelGGL((rq_scan_tail_kernel<NT, NV, EPI>), dim3((unsigned)(scan_grid + chunks * tail_B)), dim3(256), lds, stream, sa, ta, scan_grid, tc);
     return hipGetLastError();
 }
 
 template <int EPI>
-static hipError_t rq_scan_tail_launch_e(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, bool nt, int scan_grid, bool tail_first, hipStream_t stream) {
+static hipError_t rq_scan_tail_launch_e(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, bool nt, int scan_grid, bool tail_first, hipStream_t stream,
+                                        hipEvent_t e0, hipEvent_t e1) {
     if (scan_grid <= 0 || tail_B < 0) return hipErrorInvalidValue;   // tail_B = 0: development (the fused kernel without tail workgroups)
     if (ta.m < 1 || ta.m > RQ_FAST_MAX_M || ta.k < 1 || ta.k > RQ_FAST_MAX_K) return hipErrorInvalidValue;
     // Riding tails: as few workgroups as keep every CU's third slot busy once (~256): each tail workgroup costs the
@@ -351,15 +360,17 @@ static hipError_t rq_scan_tail_launch_e(const RqScanArgs& sa, const RqTailArgs& 
     // 2048 bins 252.4 us).  The stand-alone launch (rq_tail_launch) prefers more, smaller ones: lower latency.
     const auto wgs = [&](int nv) { return ((ta.nbins + 512 * nv - 1) / (512 * nv)) * tail_B; };
     const int nv = wgs(1) <= 384 ? 1 : (wgs(4) <= 384 ? 4 : 8);
-    if (nt) return nv == 1 ? rq_scan_tail_launch_t<true, 1, EPI>(sa, ta, tail_B, scan_grid, tail_first, stream)
-                 : nv == 4 ? rq_scan_tail_launch_t<true, 4, EPI>(sa, ta, tail_B, scan_grid, tail_first, stream)
-                           : rq_scan_tail_launch_t<true, 8, EPI>(sa, ta, tail_B, scan_grid, tail_first, stream);
-    return nv == 1 ? rq_scan_tail_launch_t<false, 1, EPI>(sa, ta, tail_B, scan_grid, tail_first, stream)
-         : nv == 4 ? rq_scan_tail_launch_t<false, 4, EPI>(sa, ta, tail_B, scan_grid, tail_first, stream)
-                   : rq_scan_tail_launch_t<false, 8, EPI>(sa, ta, tail_B, scan_grid, tail_first, stream);
+    if (nt) return nv == 1 ? rq_scan_tail_launch_t<true, 1, EPI>(sa, ta, tail_B, scan_grid, tail_first, stream, e0, e1)
+                 : nv == 4 ? rq_scan_tail_launch_t<true, 4, EPI>(sa, ta, tail_B, scan_grid, tail_first, stream, e0, e1)
+                           : rq_scan_tail_launch_t<true, 8, EPI>(sa, ta, tail_B, scan_grid, tail_first, stream, e0, e1);
+    return nv == 1 ? rq_scan_tail_launch_t<false, 1, EPI>(sa, ta, tail_B, scan_grid, tail_first, stream, e0, e1)
+         : nv == 4 ? rq_scan_tail_launch_t<false, 4, EPI>(sa, ta, tail_B, scan_grid, tail_first, stream, e0, e1)
+                   : rq_scan_tail_launch_t<false, 8, EPI>(sa, ta, tail_B, scan_grid, tail_first, stream, e0, e1);
 }
 
 // epi: selection form of the scan workgroups (0 = compare / select, 1 = positions inside the scores)
-hipError_t rq_scan_tail_launch(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, bool nt, int scan_grid, int epi, bool tail_first, hipStream_t stream) {
-    return epi ? rq_scan_tail_launch_e<1>(sa, ta, tail_B, nt, scan_grid, tail_first, stream) : rq_scan_tail_launch_e<0>(sa, ta, tail_B, nt, scan_grid, tail_first, stream);
+hipError_t rq_scan_tail_launch(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, bool nt, int scan_grid, int epi, bool tail_first, hipStream_t stream,
+                               hipEvent_t e0, hipEvent_t e1) {
+    return epi ? rq_scan_tail_launch_e<1>(sa, ta, tail_B, nt, scan_grid, tail_first, stream, e0, e1)
+               : rq_scan_tail_launch_e<0>(sa, ta, tail_B, nt, scan_grid, tail_first, stream, e0, e1);
 }

@@ -18,6 +18,8 @@
 //   * QG = 2: a wave keeps 2 x 16 queries in registers (192 VGPRs, one wave per SIMD) and every fragment it reads feeds
 //     two MFMAs -- half the LDS reads per query of the 8-wave form.
 // Replaces the arithmetic of reference rag_uq/streaming_index.py:355-359 (collection.query), like rq_scan.hip.
+#include <hip/hip_ext.h>
+
 #include "rq_device.h"
 #include "rq_kernels.h"
 
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(64 * QW, OCC) void rq_scanw_kernel(RqScanArgs a) {
 }
 
 template <bool NT, int D, int OCC, int QW, int QG, int EPI = 0, int DBG = 0, int PRIO = 0>
-static hipError_t rq_scanw_launch_t(const RqScanArgs& a, int grid, hipStream_t stream) {
+static hipError_t rq_scanw_launch_t(const RqScanArgs& a, int grid, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
     constexpr size_t lds = rq_scanw_lds_bytes(QW, QG);
     static_assert(lds <= 160 * 1024, "LDS of one workgroup");
     static unsigned long long attr_done = 0;   // one bit per device
@@ -328,7 +330,8 @@ static hipError_t rq_scanw_launch_t(const RqScanArgs& a, int grid, hipStream_t s
         if (e != hipSuccess) return e;
         attr_done |= 1ull << (dev & 63);
     }
-    hipLaunchKernelGGL((rq_scanw_kernel<NT, D, OCC, QW, QG, EPI, DBG, PRIO>), dim3(grid), dim3(64 * QW), lds, stream, a);
+    if (e0 && e1) hipExtLaunchKernelGGL((rq_scanw_kernel<NT, D, OCC, QW, QG, EPI, DBG, PRIO>), dim3(grid), dim3(64 * QW), (uint32_t)lds, stream, e0, e1, 0, a);
+    else hipLaunchKernelGGL((rq_scanw_kernel<NT, D, OCC, QW, QG, EPI, DBG, PRIO>), dim3(grid), dim3(64 * QW), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -345,11 +348,11 @@ static hipError_t rq_scanw_launch_t(const RqScanArgs& a, int grid, hipStream_t s
 //      (A/B of the two-waves-per-SIMD levers of MI355X_MICROARCH.md: neither beats 0 once the accumulators alternate)
 //   90..95  timing experiments, results invalid: no selection / no LDS fragment reads / no MFMAs, on variant 4's (90-92)
 //      and variant 0's (93-95) shape
-hipError_t rq_scan_wide_launch(const RqScanArgs& a, int variant, int queries, bool nt, int grid, hipStream_t stream) {
+hipError_t rq_scan_wide_launch(const RqScanArgs& a, int variant, int queries, bool nt, int grid, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
     if (grid <= 0) return hipErrorInvalidValue;
 #define RQW_CASE(V, DD, OO, QQ, GG, ...) \
     if (variant == V && queries == 16 * QQ * GG) \
-        return nt ? rq_scanw_launch_t<true, DD, OO, QQ, GG, ##__VA_ARGS__>(a, grid, stream) : rq_scanw_launch_t<false, DD, OO, QQ, GG, ##__VA_ARGS__>(a, grid, stream);
+        return nt ? rq_scanw_launch_t<true, DD, OO, QQ, GG, ##__VA_ARGS__>(a, grid, stream, e0, e1) : rq_scanw_launch_t<false, DD, OO, QQ, GG, ##__VA_ARGS__>(a, grid, stream, e0, e1);
     RQW_CASE(0, 12, 2, 8, 1, 1) RQW_CASE(1, 4, 2, 8, 1, 1) RQW_CASE(2, 2, 2, 8, 2, 1)
     RQW_CASE(4, 4, 2, 8, 1, 0) RQW_CASE(5, 4, 1, 4, 2, 1)
     RQW_CASE(6, 12, 2, 8, 1, 1, 0, 2) RQW_CASE(7, 12, 2, 8, 1, 1, 0, 1)

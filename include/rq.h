@@ -114,7 +114,7 @@ int rq_merge_keys_device(const uint64_t* d_keys_in, int n_per_query, int B, int 
 /* Tuning / test hooks: "kstage" (1: an LDS stage holds whole rows, 2: half rows), "ring" (LDS stages 2..6; the
  * (kstage, ring, prefetch) triples built are listed in csrc/rq_scan.hip, others fail with RQ_EHIP at search time),
  * "wg_per_cu", "nt" (non-temporal corpus loads: 0, 1, -1 = auto), "slack_bins" (extra bins beyond k, -1 = auto),
- * "eps" (certificate bound, <0 = derived default), "profile" (record HIP events around every scan launch; "profile_stride" n: around every n-th),
+ * "eps" (certificate bound, <0 = derived default), "profile" (HIP events on every scan launch, attached to the dispatch; "profile_stride" n: on every n-th; "profile_legacy" 1: hipEventRecord around it),
  * "prefetch" (LDS fragments read ahead of their MFMAs: 1, 4, 6, 12), "fast_tail" (0 = generic sorted tail),
  * "pipeline" (see rq_search_flush_device), "wide_batch" (calls of more than 64 queries: 0 = passes of 64 only, 1 = passes of
  * 256 / 128 / 64, 3 = 128 / 64, 2 = round 1's 8-wave 128-query pass), "wide128" / "wide256" (variant of csrc/rq_scan_wide.hip),
