@@ -3,23 +3,11 @@
 // One rq_index = one row shard resident on one MI355X.  Layout in HBM:
 //   x          [cap][768] fp16, cap % 64 == 0, rows >= n are zero      (the only large array)
 //   rownorm64  [cap]      fp64 L2 norm of the stored row               (exact re-score)
-//   inv_norm   [cap]      fp32 1/norm, 0 for zero rows, NaN for pad rows (scan, cosine)
-//   ones       [cap]      fp32 1.0 for rows < n, NaN beyond             (scan, inner product; lazy)
+//   inv_norm   [cap]      fp32 2^-12 / norm, 0 for zero rows, NaN for pad rows (scan, cosine; the queries carry 2^12)
+//   ones       [cap]      fp32 2^-12 for rows < n, NaN beyond                  (scan, inner product; lazy)
 // plus one workspace per stream (query fragments, per-bin scan records, bin keys, candidate keys).
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <map>
-#include <string>
-#include <vector>
-
-#include "../../include/rq.h"
-#include "rq_device.h"
-#include "rq_kernels.h"
+// Internal definitions: rq_index.h; the multi-device parent (n_devices > 1): rq_multi.hip.
+#include "rq_index.h"
 
 hipError_t rq_rowscale_launch(const double* norm64, int64_t row_begin, int64_t row_end, float* inv_norm, hipStream_t stream);
 
@@ -27,149 +15,32 @@ hipError_t rq_rowscale_launch(const double* norm64, int64_t row_begin, int64_t r
 // errors
 // ---------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
-static int set_err(int code, const char* fmt, ...) {
+int set_err(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     return code;
 }
-#define HIPCHK(expr)                                                                                    \
-    do {                                                                                                \
-        hipError_t e_ = (expr);                                                                         \
-        if (e_ != hipSuccess) return set_err(RQ_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
+const char* rq_err_text() { return g_err; }
 
-// ---------------------------------------------------------------------------------------------
-// index object
-// ---------------------------------------------------------------------------------------------
-struct Workspace {
-    int bcap = 0;                 // query slots (multiple of 64)
-    int64_t bins_stride = 0;      // bin records per query
-    int64_t binkeys_cap = 0;      // entries per query
-    size_t cand_elems = 0;        // candidate keys allocated in total (queries of a call x keys per query)
-    _Float16* qh = nullptr;
-    float* q32 = nullptr;
-    double* qn = nullptr;
-    uint2* bins = nullptr;        // [bcap][bins_stride] scan output: one record per (query, quad), see rq_device.h
-    uint64_t* binkeys = nullptr;
-    uint64_t* cand = nullptr;
-    float* wgmax = nullptr;       // [bcap][RQ_WGMAX_STRIDE]
-    int* rowcount = nullptr;      // [bcap] fast tail: candidate rows appended so far
-    float* thr = nullptr;         // [bcap]
-    int* done = nullptr;          // [bcap] fast tail: workgroups of the query that have finished
-    int* ovf = nullptr;           // [bcap] fast tail: a workgroup found more bins / rows than it could hold
-    bool counters_zero = false;   // rowcount/done/ovf known to be all zero (the tail kernel leaves them so)
-    // staging for rq_search_fixup_device
-    int fix_bcap = 0, fix_k = 0;
-    float* fix_q = nullptr;
-    float* fix_scores = nullptr;
-    int64_t* fix_rows = nullptr;
-    uint64_t* fix_keys = nullptr;
-    int* fix_status = nullptr;
-};
-
-// Per caller stream: two workspaces (alternating calls), an internal tail stream and the events that
-// order scan -> tail and tail -> reuse of the same workspace two calls later ("pipeline" option).
-struct StreamCtx {
-    Workspace w[2];
-    hipStream_t tail = nullptr;
-    hipEvent_t ev_scan[2] = {nullptr, nullptr};
-    hipEvent_t ev_tail[2] = {nullptr, nullptr};
-    bool tail_pending[2] = {false, false};
-    uint64_t calls = 0;
-    // "pipeline" = 2: the tail of the last search waits here and rides along with the next scan launch of the stream
-    bool fused_pending = false;
-    RqTailArgs fused_tail;
-    int fused_B = 0;
-};
-
-// Default scan variant: half-row stages (kstage 2), ring of 3, one LDS fragment ahead (prefetch 1, <= 168 VGPRs),
-// 2 workgroups per CU.  All variants stream at the same rate; this one leaves room on every CU (registers:
-// 2 x 168 + 168 <= 512 VGPRs; LDS: 3 x 53 760 B <= 160 KB) for a tail workgroup to be resident beside the scan.
-struct rq_index {
-    int dim = 0, device = 0, cu_count = 256;
-    int64_t n = 0, cap = 0, row_offset = 0;
-    char* x = nullptr;
-    double* rownorm64 = nullptr;
-    float* inv_norm = nullptr;
-    float* ones = nullptr;
-    int64_t ones_valid = 0;
-    double* d_maxnorm = nullptr;   // device: bits of the running maxima {row norm, relative, absolute fp16-subnormal mass of a row}
-    double max_row_norm = 0.0, max_sub_rel = 0.0, max_sub_abs = 0.0;
-    unsigned long long* dbg_stamps = nullptr;   // development (rq_debug_stamps)
-    uint64_t scan_seq = 0;         // scan launches seen while profile = 1 (every profile_stride-th one is timed)
-    // options
-    int ring = 3, prefetch = 1, kstage = 2, wide_batch = 1, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, profile_stride = 1, scan_nostore = 0, fast_tail = 1, pipeline = 0, tail_stop = 0, poison_cand = 0, wide128 = 0, wide256 = 11, epi = 1, tail_first = 0, profile_legacy = 0;
-    double eps = -1.0;
-    std::map<hipStream_t, StreamCtx> ctx;
-    hipStream_t own_stream = nullptr;
-    // host-call staging
-    float* h_dq = nullptr; float* h_dscores = nullptr; int64_t* h_drows = nullptr; int* h_dstatus = nullptr;
-    int h_bcap = 0, h_kcap = 0;
-    // small blocking searches (the reference's one-query-per-call pattern): results leave in ONE copy into pinned memory
-    char* hs_dev = nullptr; char* hs_pin = nullptr; float* hs_pin_q = nullptr; size_t hs_bytes = 0, hs_qfloats = 0;
-    bool hs_small = false;         // which staging path the search in flight uses (search_begin / search_end)
-    // Multi-device parent (rq_index_create with n_devices > 1): no device memory of its own, one single-device child per
-    // entry of device_ids.  Every appended block is cut into contiguous pieces, piece j goes to child j, so a child holds
-    // several segments of global ids; seg_local[j] = local start of each segment (+ end sentinel), seg_global[j] = its
-    // global start.  Local order inside a child is monotone in the global id.
-    std::vector<rq_index*> shards;
-    std::vector<std::vector<int64_t>> seg_local, seg_global;
-    // timing
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-    size_t ev_used = 0;
-    rq_timing t = {};
-};
-
-// Derived bound on |approximate scan score - exact score| for unit queries and cosine scaling:
-//   fp16 rounding of the unit query (2^-11 relative, 2^-25 absolute in the subnormal range),
-//   fp32 accumulation inside the MFMA chain (<= 4 * 768 * 2^-24 of sum|q_i x_i| <= 1, conservative),
-//   two fp32 roundings for the row scale,
-//   2^-17 relative for the row position that rq_scan_wide.hip writes into the 6 low mantissa bits of a score
-//   (4.88e-4 + 8e-7 + 1.83e-4 + 1.2e-7 + 7.6e-6 = 6.8e-4).  See DESIGN.md "certificate".
-static const float RQ_EPS_DEFAULT = 7.0e-4f;
-
-// Bound on |scan score - exact score| handed to the tail kernels, which use it as is for cosine and multiplied by the
-// largest row norm for the inner product: the derived bound (or option "eps") plus what the matrix cores drop by flushing
-// the fp16-subnormal elements of a stored row (rq_select.hip rq_rownorm_kernel).
-static float scan_eps(const rq_index* idx, int metric) {
+float scan_eps(const rq_index* idx, int metric) {
     const double base = idx->eps < 0 ? (double)RQ_EPS_DEFAULT : idx->eps;
     if (metric == RQ_METRIC_COSINE) return (float)(base + idx->max_sub_rel * (1.0 + 1e-6));
     return (float)(base + (idx->max_row_norm > 0.0 ? idx->max_sub_abs / idx->max_row_norm * (1.0 + 1e-6) : 0.0));
 }
-// Beyond this bound the approximate pass cannot narrow anything down (cosine scores live in [-1, 1]): scan exactly.
-static const float RQ_EPS_USELESS = 0.05f;
 
 static int nb_default(const rq_index* idx, int k) {
     const int slack = idx->slack_bins >= 0 ? idx->slack_bins : std::max(8, k / 8);
     return k + slack;
 }
-static const int RQ_NB_MAX = 3071;
-
-// Every entry point works on the index's device and puts the caller's current device back on return (a caller that
-// holds tensors on another GPU, e.g. torch with several devices, must not find its device switched under it).
-struct DeviceGuard {
-    int prev = -1, dev = -1;
-    bool ok = true;
-    explicit DeviceGuard(int d) : dev(d) {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
-    }
-    ~DeviceGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
-    DeviceGuard(const DeviceGuard&) = delete;
-    DeviceGuard& operator=(const DeviceGuard&) = delete;
-};
-#define RQ_ON_DEVICE(idx)                                                                                  \
-    DeviceGuard dg_((idx)->device);                                                                        \
-    if (!dg_.ok) return set_err(RQ_EHIP, "cannot select device %d", (idx)->device)
 
 extern "C" int rq_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
-extern "C" const char* rq_last_error(void) { return g_err; }
+extern "C" const char* rq_last_error(void) { return rq_err_text(); }
 extern "C" const char* rq_version(void) { return "rq-hip 0.1 (gfx950)"; }
 
 static int flush_all(rq_index* idx);   // launches every tail still waiting for a scan ("pipeline" = 2)
@@ -211,12 +82,10 @@ static int grow(rq_index* idx, int64_t want_rows) {
     return RQ_OK;
 }
 
-static rq_index* multi_create(int dim, int n_devices, const int* device_ids);
-
 extern "C" rq_index* rq_index_create(int dim, int n_devices, const int* device_ids) {
     if (dim < 1 || dim > RQ_MAX_DIM) { set_err(RQ_EINVAL, "dim %d outside 1..%d", dim, RQ_MAX_DIM); return nullptr; }
     if (n_devices < 1 || n_devices > 64 || !device_ids) { set_err(RQ_EINVAL, "n_devices %d outside 1..64 or no device list", n_devices); return nullptr; }
-    if (n_devices > 1) return multi_create(dim, n_devices, device_ids);
+    if (n_devices > 1) return rq_multi_create(dim, n_devices, device_ids);
     const int ndev = rq_device_count();
     if (ndev <= 0) { set_err(RQ_ENODEVICE, "no HIP device visible: the gfx950 backend has no CPU fallback"); return nullptr; }
     if (device_ids[0] < 0 || device_ids[0] >= ndev) { set_err(RQ_EINVAL, "device %d outside 0..%d", device_ids[0], ndev - 1); return nullptr; }
@@ -276,7 +145,7 @@ extern "C" void rq_index_destroy(rq_index* idx) {
     for (auto& ev : idx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (idx->hs_pin) (void)hipHostFree(idx->hs_pin);
     if (idx->hs_pin_q) (void)hipHostFree(idx->hs_pin_q);
-    void* p[] = {idx->x, idx->rownorm64, idx->inv_norm, idx->ones, idx->d_maxnorm, idx->h_dq, idx->h_dscores, idx->h_drows, idx->h_dstatus, idx->hs_dev, idx->dbg_stamps};
+    void* p[] = {idx->add_stage, idx->x, idx->rownorm64, idx->inv_norm, idx->ones, idx->d_maxnorm, idx->h_dq, idx->h_dscores, idx->h_drows, idx->h_dstatus, idx->hs_dev, idx->dbg_stamps};
     for (void* q : p) if (q) (void)hipFree(q);
     if (idx->own_stream) (void)hipStreamDestroy(idx->own_stream);
     delete idx;
@@ -341,40 +210,42 @@ extern "C" int rq_index_add_f32_device(rq_index* idx, const float* d_rows, int64
     return add_device_common(idx, d_rows, n_rows, true, normalize);
 }
 
-static int multi_add(rq_index* idx, const void* rows, int64_t n_rows, bool is_f32, int normalize);
-
-static int add_host_common(rq_index* idx, const void* rows, int64_t n_rows, bool is_f32, int normalize) {
+int rq_add_host_common(rq_index* idx, const void* rows, int64_t n_rows, bool is_f32, int normalize) {
     if (!idx || (!rows && n_rows > 0) || n_rows < 0) return set_err(RQ_EINVAL, "bad add arguments");
     if (n_rows == 0) return RQ_OK;
-    if (!idx->shards.empty()) return multi_add(idx, rows, n_rows, is_f32, normalize);
+    if (!idx->shards.empty()) return rq_multi_add(idx, rows, n_rows, is_f32, normalize);
     RQ_ON_DEVICE(idx);
     if (int r = grow(idx, idx->n + n_rows)) return r;
-    // stream the host rows through a bounded device staging buffer
+    // stream the host rows through a bounded device staging buffer, kept between calls (an indexing run appends
+    // 100 documents at a time: no hipMalloc / hipFree per batch); a buffer beyond 16 MiB is given back after the call
     const size_t esz = is_f32 ? 4 : 2;
     const int64_t chunk = std::max<int64_t>(1, ((int64_t)256 << 20) / (int64_t)(idx->dim * esz));
-    void* stage = nullptr;
-    HIPCHK(hipMalloc(&stage, (size_t)std::min(chunk, n_rows) * idx->dim * esz));
+    const size_t need = (size_t)std::min(chunk, n_rows) * idx->dim * esz;
+    if (need > idx->add_stage_bytes) {
+        if (idx->add_stage) (void)hipFree(idx->add_stage);
+        idx->add_stage = nullptr; idx->add_stage_bytes = 0;
+        HIPCHK(hipMalloc(&idx->add_stage, need));
+        idx->add_stage_bytes = need;
+    }
     int rc = RQ_OK;
     for (int64_t off = 0; off < n_rows && rc == RQ_OK; off += chunk) {
         const int64_t m = std::min(chunk, n_rows - off);
-        hipError_t e = hipMemcpy(stage, (const char*)rows + (size_t)off * idx->dim * esz, (size_t)m * idx->dim * esz, hipMemcpyHostToDevice);
+        hipError_t e = hipMemcpy(idx->add_stage, (const char*)rows + (size_t)off * idx->dim * esz, (size_t)m * idx->dim * esz, hipMemcpyHostToDevice);
         if (e != hipSuccess) { rc = set_err(RQ_EHIP, "H2D copy failed: %s", hipGetErrorString(e)); break; }
-        rc = add_device_common(idx, stage, m, is_f32, normalize);
+        rc = add_device_common(idx, idx->add_stage, m, is_f32, normalize);
     }
-    (void)hipFree(stage);
+    if (idx->add_stage_bytes > ((size_t)16 << 20)) { (void)hipFree(idx->add_stage); idx->add_stage = nullptr; idx->add_stage_bytes = 0; }
     return rc;
 }
-extern "C" int rq_index_add_f16(rq_index* idx, const uint16_t* rows, int64_t n_rows) { return add_host_common(idx, rows, n_rows, false, 0); }
+extern "C" int rq_index_add_f16(rq_index* idx, const uint16_t* rows, int64_t n_rows) { return rq_add_host_common(idx, rows, n_rows, false, 0); }
 extern "C" int rq_index_add_f32(rq_index* idx, const float* rows, int64_t n_rows, int normalize) {
-    return add_host_common(idx, rows, n_rows, true, normalize);
+    return rq_add_host_common(idx, rows, n_rows, true, normalize);
 }
-
-static int multi_get_rows(const rq_index* idx, int64_t row_begin, int64_t n_rows, uint16_t* out);
 
 extern "C" int rq_index_get_rows_f16(const rq_index* idx, int64_t row_begin, int64_t n_rows, uint16_t* out) {
     if (!idx || !out || row_begin < 0 || n_rows < 0 || row_begin + n_rows > idx->n) return set_err(RQ_EINVAL, "row range outside the index");
     if (n_rows == 0) return RQ_OK;
-    if (!idx->shards.empty()) return multi_get_rows(idx, row_begin, n_rows, out);
+    if (!idx->shards.empty()) return rq_multi_get_rows(idx, row_begin, n_rows, out);
     RQ_ON_DEVICE(idx);
     HIPCHK(hipMemcpy2D(out, (size_t)idx->dim * 2, idx->x + (size_t)row_begin * RQ_DPAD * 2, (size_t)RQ_DPAD * 2, (size_t)idx->dim * 2,
                        (size_t)n_rows, hipMemcpyDeviceToHost));
@@ -850,7 +721,7 @@ extern "C" int rq_search_fixup_device(rq_index* idx, const float* d_queries, int
 // The blocking host-buffer search in two halves, so that a multi-device parent can enqueue on every device before it
 // waits for any: search_begin stages the queries and enqueues the search on the index's own stream, search_end waits,
 // repairs uncertified queries and hands the results over.
-static int search_begin(rq_index* idx, const float* queries, int B, int k, int metric) {
+int rq_search_begin(rq_index* idx, const float* queries, int B, int k, int metric) {
     RQ_ON_DEVICE(idx);
     if (B > idx->h_bcap || k > idx->h_kcap) {
         const int nb = std::max(B, idx->h_bcap), nk = std::max(k, idx->h_kcap);
@@ -894,7 +765,7 @@ static int search_begin(rq_index* idx, const float* queries, int B, int k, int m
     return rq_search_device(idx, idx->h_dq, B, k, metric, idx->h_dscores, idx->h_drows, nullptr, idx->h_dstatus, s);
 }
 
-static int search_end(rq_index* idx, int B, int k, int metric, float* out_scores, int64_t* out_rows) {
+int rq_search_end(rq_index* idx, int B, int k, int metric, float* out_scores, int64_t* out_rows) {
     RQ_ON_DEVICE(idx);
     hipStream_t s = idx->own_stream;
     if (idx->hs_small) {
@@ -924,101 +795,11 @@ static int search_end(rq_index* idx, int B, int k, int metric, float* out_scores
     return RQ_OK;
 }
 
-static int multi_search(rq_index* idx, const float* queries, int B, int k, int metric, float* out_scores, int64_t* out_rows);
-
 extern "C" int rq_search(rq_index* idx, const float* queries, int B, int k, int metric, float* out_scores, int64_t* out_rows) {
     if (int r = check_search_args(idx, queries, B, k, metric, out_scores, out_rows)) return r;
-    if (!idx->shards.empty()) return multi_search(idx, queries, B, k, metric, out_scores, out_rows);
-    if (int r = search_begin(idx, queries, B, k, metric)) return r;
-    return search_end(idx, B, k, metric, out_scores, out_rows);
-}
-
-// ---------------------------------------------------------------------------------------------
-// multi-device parent: contiguous row blocks per device inside the library
-// ---------------------------------------------------------------------------------------------
-static rq_index* multi_create(int dim, int n_devices, const int* device_ids) {
-    rq_index* p = new rq_index();
-    p->dim = dim;
-    p->device = device_ids[0];
-    for (int j = 0; j < n_devices; ++j) {
-        rq_index* c = rq_index_create(dim, 1, device_ids + j);   // (the same device may be named several times)
-        if (!c) { rq_index_destroy(p); return nullptr; }
-        p->shards.push_back(c);
-        p->seg_local.push_back({0});
-        p->seg_global.push_back({});
-    }
-    return p;
-}
-
-static int multi_add(rq_index* idx, const void* rows, int64_t n_rows, bool is_f32, int normalize) {
-    if ((uint64_t)idx->row_offset + (uint64_t)idx->n + (uint64_t)n_rows >= 0xffffffffull)
-        return set_err(RQ_EUNSUPPORTED, "row ids beyond 2^32-1 are not supported");
-    const int64_t g = (int64_t)idx->shards.size(), per = (n_rows + g - 1) / g;
-    const size_t esz = is_f32 ? 4 : 2;
-    for (int64_t j = 0; j < g; ++j) {
-        const int64_t lo = std::min(j * per, n_rows), hi = std::min((j + 1) * per, n_rows);
-        if (hi <= lo) continue;
-        if (int r = add_host_common(idx->shards[j], (const char*)rows + (size_t)lo * idx->dim * esz, hi - lo, is_f32, normalize)) {
-            // pieces 0..j-1 of this block are already stored: the parent is no longer a prefix of what the caller sent
-            return set_err(r, "multi-device append failed on device slot %lld after %lld of %lld rows of the block were stored: %s",
-                           (long long)j, (long long)lo, (long long)n_rows, std::string(g_err).c_str());
-        }
-        idx->seg_global[j].push_back(idx->n + lo);
-        idx->seg_local[j].push_back(idx->seg_local[j].back() + (hi - lo));
-    }
-    idx->n += n_rows;
-    return RQ_OK;
-}
-
-static int multi_get_rows(const rq_index* idx, int64_t row_begin, int64_t n_rows, uint16_t* out) {
-    const int64_t row_end = row_begin + n_rows;
-    for (size_t j = 0; j < idx->shards.size(); ++j)
-        for (size_t sgi = 0; sgi < idx->seg_global[j].size(); ++sgi) {
-            const int64_t g0 = idx->seg_global[j][sgi], len = idx->seg_local[j][sgi + 1] - idx->seg_local[j][sgi];
-            const int64_t lo = std::max(g0, row_begin), hi = std::min(g0 + len, row_end);
-            if (hi <= lo) continue;
-            if (int r = rq_index_get_rows_f16(idx->shards[j], idx->seg_local[j][sgi] + (lo - g0), hi - lo, out + (size_t)(lo - row_begin) * idx->dim)) return r;
-        }
-    return RQ_OK;
-}
-
-static int multi_search(rq_index* idx, const float* queries, int B, int k, int metric, float* out_scores, int64_t* out_rows) {
-    const size_t g = idx->shards.size();
-    idx->t.searches++;
-    idx->t.queries += B;
-    std::vector<size_t> live;
-    for (size_t j = 0; j < g; ++j)
-        if (idx->shards[j]->n > 0) {
-            if (int r = search_begin(idx->shards[j], queries, B, k, metric)) return r;   // every device is busy before any is waited for
-            live.push_back(j);
-        }
-    std::vector<float> sc((size_t)B * k);
-    std::vector<int64_t> rw((size_t)B * k);
-    std::vector<std::vector<uint64_t>> keys((size_t)B);
-    for (size_t j : live) {
-        if (int r = search_end(idx->shards[j], B, k, metric, sc.data(), rw.data())) return r;
-        const std::vector<int64_t>& sl = idx->seg_local[j];
-        const std::vector<int64_t>& sg = idx->seg_global[j];
-        for (int q = 0; q < B; ++q)
-            for (int i = 0; i < k; ++i) {
-                const int64_t lr = rw[(size_t)q * k + i];
-                if (lr < 0) continue;
-                const size_t sgi = (size_t)(std::upper_bound(sl.begin(), sl.end() - 1, lr) - sl.begin()) - 1;   // segment that holds the local row
-                const int64_t grow = sg[sgi] + (lr - sl[sgi]);
-                keys[(size_t)q].push_back(rq_make_key(sc[(size_t)q * k + i], (uint32_t)grow));
-            }
-    }
-    for (int q = 0; q < B; ++q) {   // canonical order: score descending, then global row ascending = key descending
-        std::vector<uint64_t>& kq = keys[(size_t)q];
-        const size_t m = std::min<size_t>((size_t)k, kq.size());
-        std::partial_sort(kq.begin(), kq.begin() + m, kq.end(), std::greater<uint64_t>());
-        for (int i = 0; i < k; ++i) {
-            const bool v = (size_t)i < m;
-            out_scores[(size_t)q * k + i] = v ? rq_key_score(kq[(size_t)i]) : 0.f;
-            out_rows[(size_t)q * k + i] = v ? idx->row_offset + (int64_t)rq_key_index(kq[(size_t)i]) : -1;
-        }
-    }
-    return RQ_OK;
+    if (!idx->shards.empty()) return rq_multi_search(idx, queries, B, k, metric, out_scores, out_rows);
+    if (int r = rq_search_begin(idx, queries, B, k, metric)) return r;
+    return rq_search_end(idx, B, k, metric, out_scores, out_rows);
 }
 
 extern "C" int rq_merge_keys_device(const uint64_t* d_keys_in, int n_per_query, int B, int k, float* d_scores, int64_t* d_rows,

@@ -1,0 +1,158 @@
+// rq_index.h -- internal definitions shared by rq_api.hip (single-device index, the C ABI) and rq_multi.hip (the
+// multi-device parent): error channel, the index object, the per-stream workspaces, the device guard.
+// Not part of the public boundary (that is include/rq.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/rq.h"
+#include "rq_device.h"
+#include "rq_kernels.h"
+
+#define RQ_INTERNAL __attribute__((visibility("hidden")))
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+RQ_INTERNAL int set_err(int code, const char* fmt, ...);   // stores the message of rq_last_error() (thread local), returns code
+RQ_INTERNAL const char* rq_err_text();
+#define HIPCHK(expr)                                                                                    \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return set_err(RQ_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// index object
+// ---------------------------------------------------------------------------------------------
+struct Workspace {
+    int bcap = 0;                 // query slots (multiple of 64)
+    int64_t bins_stride = 0;      // bin records per query
+    int64_t binkeys_cap = 0;      // entries per query
+    size_t cand_elems = 0;        // candidate keys allocated in total (queries of a call x keys per query)
+    _Float16* qh = nullptr;
+    float* q32 = nullptr;
+    double* qn = nullptr;
+    uint2* bins = nullptr;        // [bcap][bins_stride] scan output: one record per (query, quad), see rq_device.h
+    uint64_t* binkeys = nullptr;
+    uint64_t* cand = nullptr;
+    float* wgmax = nullptr;       // [bcap][RQ_WGMAX_STRIDE]
+    int* rowcount = nullptr;      // [bcap] fast tail: candidate rows appended so far
+    float* thr = nullptr;         // [bcap]
+    int* done = nullptr;          // [bcap] fast tail: workgroups of the query that have finished
+    int* ovf = nullptr;           // [bcap] fast tail: a workgroup found more bins / rows than it could hold
+    bool counters_zero = false;   // rowcount/done/ovf known to be all zero (the tail kernel leaves them so)
+    // staging for rq_search_fixup_device
+    int fix_bcap = 0, fix_k = 0;
+    float* fix_q = nullptr;
+    float* fix_scores = nullptr;
+    int64_t* fix_rows = nullptr;
+    uint64_t* fix_keys = nullptr;
+    int* fix_status = nullptr;
+};
+
+// Per caller stream: two workspaces (alternating calls), an internal tail stream and the events that
+// order scan -> tail and tail -> reuse of the same workspace two calls later ("pipeline" option).
+struct StreamCtx {
+    Workspace w[2];
+    hipStream_t tail = nullptr;
+    hipEvent_t ev_scan[2] = {nullptr, nullptr};
+    hipEvent_t ev_tail[2] = {nullptr, nullptr};
+    bool tail_pending[2] = {false, false};
+    uint64_t calls = 0;
+    // "pipeline" = 2: the tail of the last search waits here and rides along with the next scan launch of the stream
+    bool fused_pending = false;
+    RqTailArgs fused_tail;
+    int fused_B = 0;
+};
+
+// Default scan variant: half-row stages (kstage 2), ring of 3, one LDS fragment ahead (prefetch 1, <= 168 VGPRs),
+// 2 workgroups per CU.  All variants stream at the same rate; this one leaves room on every CU (registers:
+// 2 x 168 + 168 <= 512 VGPRs; LDS: 3 x 53 760 B <= 160 KB) for a tail workgroup to be resident beside the scan.
+struct rq_index {
+    int dim = 0, device = 0, cu_count = 256;
+    int64_t n = 0, cap = 0, row_offset = 0;
+    char* x = nullptr;
+    double* rownorm64 = nullptr;
+    float* inv_norm = nullptr;
+    float* ones = nullptr;
+    int64_t ones_valid = 0;
+    double* d_maxnorm = nullptr;   // device: bits of the running maxima {row norm, relative, absolute fp16-subnormal mass of a row}
+    double max_row_norm = 0.0, max_sub_rel = 0.0, max_sub_abs = 0.0;
+    unsigned long long* dbg_stamps = nullptr;   // development (rq_debug_stamps)
+    uint64_t scan_seq = 0;         // scan launches seen while profile = 1 (every profile_stride-th one is timed)
+    // options
+    int ring = 3, prefetch = 1, kstage = 2, wide_batch = 1, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, profile_stride = 1, scan_nostore = 0, fast_tail = 1, pipeline = 0, tail_stop = 0, poison_cand = 0, wide128 = 0, wide256 = 11, epi = 1, tail_first = 0, profile_legacy = 0;
+    double eps = -1.0;
+    std::map<hipStream_t, StreamCtx> ctx;
+    hipStream_t own_stream = nullptr;
+    // host-call staging
+    float* h_dq = nullptr; float* h_dscores = nullptr; int64_t* h_drows = nullptr; int* h_dstatus = nullptr;
+    int h_bcap = 0, h_kcap = 0;
+    // small blocking searches (the reference's one-query-per-call pattern): results leave in ONE copy into pinned memory
+    char* hs_dev = nullptr; char* hs_pin = nullptr; float* hs_pin_q = nullptr; size_t hs_bytes = 0, hs_qfloats = 0;
+    void* add_stage = nullptr; size_t add_stage_bytes = 0;   // device staging of host-row appends
+    bool hs_small = false;         // which staging path the search in flight uses (search_begin / search_end)
+    // Multi-device parent (rq_index_create with n_devices > 1): no device memory of its own, one single-device child per
+    // entry of device_ids.  Every appended block is cut into contiguous pieces, piece j goes to child j, so a child holds
+    // several segments of global ids; seg_local[j] = local start of each segment (+ end sentinel), seg_global[j] = its
+    // global start.  Local order inside a child is monotone in the global id.
+    std::vector<rq_index*> shards;
+    std::vector<std::vector<int64_t>> seg_local, seg_global;
+    // timing
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t ev_used = 0;
+    rq_timing t = {};
+};
+
+// Derived bound on |approximate scan score - exact score| for unit queries and cosine scaling:
+//   fp16 rounding of the unit query (2^-11 relative, 2^-25 absolute in the subnormal range),
+//   fp32 accumulation inside the MFMA chain (<= 4 * 768 * 2^-24 of sum|q_i x_i| <= 1, conservative),
+//   two fp32 roundings for the row scale,
+//   2^-17 relative for the row position that rq_scan_wide.hip writes into the 6 low mantissa bits of a score
+//   (4.88e-4 + 8e-7 + 1.83e-4 + 1.2e-7 + 7.6e-6 = 6.8e-4).  See DESIGN.md "certificate".
+static const float RQ_EPS_DEFAULT = 7.0e-4f;
+
+// Bound on |scan score - exact score| handed to the tail kernels, which use it as is for cosine and multiplied by the
+// largest row norm for the inner product: the derived bound (or option "eps") plus what the matrix cores drop by flushing
+// the fp16-subnormal elements of a stored row (rq_select.hip rq_rownorm_kernel).
+RQ_INTERNAL float scan_eps(const rq_index* idx, int metric);
+// Beyond this bound the approximate pass cannot narrow anything down (cosine scores live in [-1, 1]): scan exactly.
+static const float RQ_EPS_USELESS = 0.05f;
+
+static const int RQ_NB_MAX = 3071;
+
+// Every entry point works on the index's device and puts the caller's current device back on return (a caller that
+// holds tensors on another GPU, e.g. torch with several devices, must not find its device switched under it).
+struct DeviceGuard {
+    int prev = -1, dev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int d) : dev(d) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define RQ_ON_DEVICE(idx)                                                                                  \
+    DeviceGuard dg_((idx)->device);                                                                        \
+    if (!dg_.ok) return set_err(RQ_EHIP, "cannot select device %d", (idx)->device)
+
+
+// ---- entry points shared between the two translation units ------------------------------------------------
+RQ_INTERNAL int rq_add_host_common(rq_index* idx, const void* rows, int64_t n_rows, bool is_f32, int normalize);
+RQ_INTERNAL int rq_search_begin(rq_index* idx, const float* queries, int B, int k, int metric);      // stage + enqueue, no wait
+RQ_INTERNAL int rq_search_end(rq_index* idx, int B, int k, int metric, float* out_scores, int64_t* out_rows);   // wait, repair, hand over
+RQ_INTERNAL rq_index* rq_multi_create(int dim, int n_devices, const int* device_ids);
+RQ_INTERNAL int rq_multi_add(rq_index* idx, const void* rows, int64_t n_rows, bool is_f32, int normalize);
+RQ_INTERNAL int rq_multi_get_rows(const rq_index* idx, int64_t row_begin, int64_t n_rows, uint16_t* out);
+RQ_INTERNAL int rq_multi_search(rq_index* idx, const float* queries, int B, int k, int metric, float* out_scores, int64_t* out_rows);
