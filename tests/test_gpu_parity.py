@@ -32,7 +32,8 @@ def corpus100k():
     idx.close()
 
 
-@pytest.mark.parametrize("B,k", [(1, 10), (5, 1), (64, 10), (70, 50), (3, 100), (130, 20), (2, 128), (2, 300), (64, 200), (5, 320), (3, 321)])
+@pytest.mark.parametrize("B,k", [(1, 10), (5, 1), (64, 10), (70, 50), (3, 100), (130, 20), (2, 128), (2, 300), (64, 200), (5, 320), (3, 321),
+                                 (300, 500), (130, 1024), (257, 321)])        # wide passes feeding the generic (k > 320) tail
 def test_cosine_topk_100k(corpus100k, B, k):
     idx, x16 = corpus100k
     _check(idx, x16, orc.synthetic_queries(B, 768, seed=4321 + B), k)
