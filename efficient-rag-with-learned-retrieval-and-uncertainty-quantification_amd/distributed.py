@@ -13,7 +13,7 @@ on the host (`merge_keys_host`).  No all-reduce, no all-to-all.
 """
 from __future__ import annotations
 
-from typing import Optional, Sequence, Tuple
+from typing import Sequence, Tuple
 
 import numpy as np
 

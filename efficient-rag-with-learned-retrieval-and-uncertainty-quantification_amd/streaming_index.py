@@ -31,7 +31,7 @@ from typing import Any, Dict, Iterator, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _native
-from .embedders import HashEmbedder, default_embedder
+from .embedders import default_embedder
 
 logger = logging.getLogger(__name__)
 

@@ -23,7 +23,7 @@ All arithmetic in float32, like torch's.
 """
 from __future__ import annotations
 
-from typing import Dict, Optional, Sequence, Tuple
+from typing import Dict, Sequence, Tuple
 
 import numpy as np
 
