@@ -41,8 +41,9 @@ __device__ __forceinline__ void rq_emit(const RqFinalCore& a, int rank, uint64_t
 
 // total: keys that wanted a slot (may exceed RQ_CAND_CAP = overflow); overflow: any other overflow seen for this query;
 // T: every row that was NOT re-scored has approximate score < T;  qn: fp64 norm of the query.
-// The keys were published by other workgroups of the SAME launch with sc1 (write-through) stores and a ticket:
-// every load of them is an sc1 load (relaxed agent-scope atomic load), never a plain one.
+// The keys were published by other workgroups of the SAME launch with sc1 (write-through) stores and a ticket; the caller
+// (rq_tail_body.h, section D) has run an agent-scope acquire + workgroup barrier before this point, and every load of the
+// keys is an sc1 load (relaxed agent-scope atomic load) besides.
 __device__ __forceinline__ void rq_final_body(const RqFinalCore& a, int total, int overflow, float T, double qn, RqFinalLds& L) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t kk = a.k < a.n_rows ? a.k : a.n_rows;

@@ -10,9 +10,10 @@
 //   C. re-scores the job rows exactly in fp64 (16 lanes per row, 8 rows of loads in flight per wave) and appends the
 //      (score, row) keys to the query's compact candidate list with 8-byte write-through (sc1) stores,
 //   D. publishes: every wave drains vmcnt, workgroup barrier, ONE lane draws a ticket (agent-scope atomic add).  The
-//      workgroup that draws the last ticket of its query reads the keys with sc1 loads only, ranks them, writes the
-//      exact top-k and the certificate, and resets the counters.  No fences: a release fence per workgroup
-//      serialises on the L2 write-back (measured +60 us per launch).
+//      workgroup that draws the last ticket of its query runs ONE agent-scope acquire (buffer_inv sc1 + vmcnt(0), then a
+//      workgroup barrier), reads the keys (sc1 loads), ranks them, writes the exact top-k and the certificate, and
+//      resets the counters.  No RELEASE fences: a release fence per workgroup serialises on the L2 write-back
+//      (measured +60 us per launch); the producer side is write-through stores + drain + barrier + ticket.
 // Exactness: a row that is not re-scored has approximate score < T (its bin's largest, second- or third-largest bound
 // is below T), so its exact score is < T + eps < s_k; see rq_final_body.h and DESIGN.md 4.2.
 // Replaces reference rag_uq/streaming_index.py:355-368 (collection.query + `1 - distance`) after the scan.

@@ -8,7 +8,8 @@
 #define RQ_TAIL_HITCAP 256     // candidate bins one workgroup can hold
 #define RQ_TAIL_JOBCAP 2048    // row jobs one workgroup can hold
 
-// LDS of one tail workgroup (20 KB): static in rq_tail_kernel, carved from the scan's LDS in the fused kernel.
+// LDS of one tail workgroup (28.8 KB: query 3 KB, hit / job lists 9 KB, 2048-key ranking buffer 16 KB): static in
+// rq_tail_kernel, carved from the scan's LDS in the fused kernel.
 struct __attribute__((aligned(16))) RqTailLds {
     float qs[RQ_DPAD];            // the raw query, shared by the four waves
     double qpart[4];
