@@ -2,8 +2,13 @@
 // Run by all 256 threads of the workgroup that drew the last ticket of its query in rq_tail_kernel (rq_tail.hip).
 //
 // The candidates are a compact list of n keys (typically k..3k: one exact re-scored row per candidate bin).
-//   n <= 2048: every key is ranked against all others through LDS (keys are unique) and written by rank;
-//   n <= 4096: keys stay in registers, k rounds of "extract the maximum" (massive exact ties only).
+//   n <= 512:  every key is ranked against all others through LDS (keys are unique) and written by rank;
+//   n <= 4096: keys stay in registers (16 per thread); a 64-round radix select over the whole workgroup finds the k-th
+//              largest key (per round: 16 ballots per wave, one LDS word per wave, one barrier), the k winners are
+//              compacted into LDS and ranked among themselves.  Document-structured corpora (16 consecutive similar
+//              passages) re-score whole 64-row bins and reach 1500-3000 candidates per query at k = 100: there the
+//              earlier forms (O(n^2) ranking up to 2048 keys, k rounds of extract-the-maximum beyond) took 260 us of a
+//              350 us tail; the select takes under 10 (tools/gpu_tail_docs.py).
 #pragma once
 #include "rq_device.h"
 #include "rq_kernels.h"   // RQ_CAND_CAP
@@ -61,7 +66,7 @@ __device__ __forceinline__ void rq_final_body(const RqFinalCore& a, int total, i
     int have = 0;
     uint64_t kth = 0;
     if (tid == 0) { L.skth = 0; L.snz = 0; }
-    if (n <= 2048) {
+    if (n <= 512) {
         int nz = 0;
         for (int j = tid; j < n; j += 256) L.skeys[j] = __hip_atomic_load(a.cand + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
@@ -88,26 +93,44 @@ __device__ __forceinline__ void rq_final_body(const RqFinalCore& a, int total, i
             const int j = i * 256 + tid;
             key[i] = j < n ? __hip_atomic_load(a.cand + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
         }
-        uint64_t best = 0;
+        // workgroup-wide count of keys >= t (t != 0): 16 ballots per wave, one LDS word per wave, one barrier
+        int round = 0;
+        auto count_ge = [&](uint64_t t) -> int {
+            int c = 0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) best = key[i] > best ? key[i] : best;
-        for (int j = 0; j < a.k; ++j) {
-            const uint64_t wm = rq_wave_max_u64(best);
-            if (lane == 0) L.wbest[j & 1][wave] = wm;
+            for (int i = 0; i < 16; ++i) c += __popcll(__ballot(key[i] >= t));
+            if (lane == 0) L.wbest[round & 1][wave] = (uint64_t)c;
             __syncthreads();
-            uint64_t win = L.wbest[j & 1][0];
-#pragma unroll
-            for (int w2 = 1; w2 < 4; ++w2) win = L.wbest[j & 1][w2] > win ? L.wbest[j & 1][w2] : win;
-            if (win == 0) break;   // uniform: candidates exhausted
-            have = j + 1;
-            if (j == kk - 1) kth = win;
-            if (tid == 0) rq_emit(a, j, win);
-            if (best == win) {   // keys are unique: exactly one thread owns the winner
-                best = 0;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { if (key[i] == win) key[i] = 0; best = key[i] > best ? key[i] : best; }
+            const int tot = (int)(L.wbest[round & 1][0] + L.wbest[round & 1][1] + L.wbest[round & 1][2] + L.wbest[round & 1][3]);
+            ++round;
+            return tot;   // uniform over the workgroup
+        };
+        const int nzt = count_ge(1);                         // non-empty keys (0 = a row beyond the shard's end)
+        have = nzt < a.k ? nzt : a.k;
+        uint64_t prefix = 1;                                 // have == nzt: every non-empty key is a winner
+        if (nzt > have) {                                    // the have-th largest key: the largest t with count(key >= t) >= have
+            prefix = 0;
+            for (int bit = 63; bit >= 0; --bit) {
+                const uint64_t t = prefix | (1ull << bit);
+                if (count_ge(t) >= have) prefix = t;         // uniform
             }
         }
+        // keys are unique, so exactly `have` keys are >= prefix: compact them, then rank them among themselves
+        if (tid == 0) L.snz = 0;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (key[i] != 0 && key[i] >= prefix) L.skeys[atomicAdd(&L.snz, 1)] = key[i];
+        __syncthreads();
+        for (int s2 = tid; s2 < have; s2 += 256) {
+            const uint64_t mine = L.skeys[s2];
+            int r = 0;
+            for (int j = 0; j < have; ++j) r += L.skeys[j] > mine ? 1 : 0;
+            rq_emit(a, r, mine);
+            if (r == kk - 1) L.skth = mine;
+        }
+        __syncthreads();
+        kth = L.skth;
     }
     for (int j = have + tid; j < a.k; j += 256) { a.out_scores[j] = 0.f; a.out_rows[j] = -1; if (a.out_keys) a.out_keys[j] = 0; }
     if (tid == 0) {

@@ -149,6 +149,44 @@ def test_dense_neighbourhoods_certify_without_a_second_pass():
     idx.close()
 
 
+@pytest.mark.parametrize("k,first_pass", [(100, True), (200, False), (320, False)])
+def test_large_candidate_sets_rank_through_the_radix_select(k, first_pass):
+    """Documents of 16 consecutive similar passages (tools/gpu_clustered.py's "documents" corpus): the best rows of a query
+    come in runs, whole 64-row bins are re-scored and a query collects one to three thousand candidate keys -- the final
+    top-k then goes through the workgroup radix select of rq_final_body.h (n > 512) instead of the all-pairs ranking.
+    Exact results, ties by row id (a duplicate run sits inside); at k = 100 nothing is widened (larger k may overflow the
+    candidate lists and take the wider pass: still exact); plain and fused (deferred) paths."""
+    import torch
+    rng = np.random.default_rng(321)
+    n, per_doc = 125_000, 16
+    docs = rng.standard_normal((n // per_doc + 1, 768)).astype(np.float32)
+    x = docs[np.arange(n) // per_doc] + 0.5 * rng.standard_normal((n, 768)).astype(np.float32)
+    x[5_000:5_040] = x[4_999]                                   # 41 identical rows across a bin boundary
+    x16 = orc.prepare_rows_f32(x, normalize=True)
+    q = rng.standard_normal((64, 768)).astype(np.float32)
+    q[0] = x16[4_999].astype(np.float32)
+    idx = nat.NativeIndex(768, 0)
+    idx.add_f16(x16)
+    _check(idx, x16, q, k)
+    t = idx.timing()
+    assert t["exact_scans"] == 0 and (t["widened"] == 0 or not first_pass), t
+    idx.set_option("pipeline", 2)
+    dev = torch.device("cuda:0")
+    dq = torch.from_numpy(q).to(dev)
+    outs = []
+    for rep in range(3):
+        sc = torch.empty((64, k), device=dev); rw = torch.empty((64, k), device=dev, dtype=torch.int64); st = torch.full((64,), 9, device=dev, dtype=torch.int32)
+        idx.search_device(dq, 64, k, 0, sc, rw, None, st, 0)
+        outs.append((sc, rw, st))
+    for sc, rw, st in outs:
+        idx.search_fixup_device(dq, 64, k, 0, sc, rw, None, st, 0)       # (flushes the deferred tail; repairs overflowed queries)
+    torch.cuda.synchronize()
+    gs, gr = orc.dense_topk(q, x16, k)
+    for sc, rw, st in outs:
+        assert int(st.sum()) == 0 and np.array_equal(rw.cpu().numpy(), gr) and float(np.abs(sc.cpu().numpy() - gs).max()) <= SCORE_TOL
+    idx.close()
+
+
 def test_clustered_near_ties():
     x16 = orc.synthetic_corpus(50_000, 768, seed=8, clustered=True)
     idx = nat.NativeIndex(768, 0)
