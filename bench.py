@@ -46,6 +46,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=0, help="caller streams the batches alternate over (0 = 1 at one GPU, 2 at several)")
     ap.add_argument("--event-stride", type=int, default=4, help="HIP events around every n-th scan launch of the timed region")
+    ap.add_argument("--no-hint", action="store_true", help="do not announce the next batch (rq_search_hint_next_device): every call prepares its own queries in a separate launch")
     ap.add_argument("--pipeline", type=int, default=2, help="deferred tails: 1 = on the library's internal stream, 2 = fused into the next scan launch")
     ap.add_argument("--workload", default="headline", choices=["headline", "config2", "config3", "config4"],
                     help="headline = BASELINE.json configs[1] (the metric); config2/3/4 = the other GPU configs at their shapes on ONE GPU "
@@ -136,6 +137,7 @@ def main() -> None:
         m_scores = torch.empty((GATHER_EVERY * B, k), device=dev)
         m_rows = torch.empty((GATHER_EVERY * B, k), device=dev, dtype=torch.int64)
     pending = {"n": 0, "ring": 0, "ev": [None, None]}
+    use_hint = args.pipeline == 2 and not args.no_hint
 
     def flush():
         """all-gather the local keys of the pending batches (one RCCL call) and merge them on the GPU"""
@@ -164,6 +166,8 @@ def main() -> None:
         s = streams[i % len(streams)]
         o = slots[j]
         keys = ring[pending["ring"]][pending["n"]] if use_comm else o["keys"]
+        if use_hint:   # the batch this stream searches next: its queries are prepared by extra workgroups of this launch
+            idx.search_hint_next_device(queries[(i + len(streams)) % N_QUERY_BATCHES], B, s.cuda_stream)
         idx.search_device(queries[j], B, k, nat.METRIC_COSINE, o["scores"], o["rows"], keys, o["status"], s.cuda_stream)
         if use_comm:
             pending["n"] += 1
@@ -315,7 +319,7 @@ def main() -> None:
         "dtype": "f16",
         "data": "synthetic",
         "config": {"workload": f"{n_total}x{DIM} fp16 corpus, batch-{B} queries, top-{k}, cosine, exact (certified) results",
-                   "rows_per_gpu": n_local, "streams": len(streams), "pipeline": args.pipeline, "gather_every": GATHER_EVERY if use_comm else 0,
+                   "rows_per_gpu": n_local, "streams": len(streams), "pipeline": args.pipeline, "next_batch_hint": use_hint, "gather_every": GATHER_EVERY if use_comm else 0,
                    "parallelism": f"row-shard x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "kernel": "rq_scan_tail_kernel" if args.pipeline == 2 else "rq_scan_kernel",

@@ -59,6 +59,7 @@ _SIGNATURES = {
     "rq_search_fixup_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "rq_search_flush_device": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rq_search_hint_next_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "rq_stream_release": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rq_merge_keys_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
@@ -216,6 +217,10 @@ class NativeIndex:
         return _check(self._lib.rq_search_fixup_device(self._h, _ptr(d_queries), int(B), int(k), int(metric), _ptr(d_scores),
                                                        _ptr(d_rows), _ptr(d_keys), _ptr(d_status), C.c_void_p(stream)),
                       "rq_search_fixup_device")
+
+    def search_hint_next_device(self, d_next_queries, B: int, stream: int = 0) -> None:
+        """Announce the queries of the NEXT search_device call on `stream` (include/rq.h: rq_search_hint_next_device)."""
+        _check(self._lib.rq_search_hint_next_device(self._h, _ptr(d_next_queries), int(B), C.c_void_p(stream)), "rq_search_hint_next_device")
 
     def search_flush_device(self, stream: int = 0) -> None:
         _check(self._lib.rq_search_flush_device(self._h, C.c_void_p(stream)), "rq_search_flush_device")

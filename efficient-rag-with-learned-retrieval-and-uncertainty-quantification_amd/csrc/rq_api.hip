@@ -124,6 +124,11 @@ static void free_ws(Workspace& w) {
 static void free_ctx(StreamCtx& c) {
     free_ws(c.w[0]);
     free_ws(c.w[1]);
+    for (int p = 0; p < 3; ++p) {
+        if (c.ring_qh[p]) (void)hipFree(c.ring_qh[p]);
+        if (c.ring_q32[p]) (void)hipFree(c.ring_q32[p]);
+        if (c.ring_qn[p]) (void)hipFree(c.ring_qn[p]);
+    }
     if (c.tail) (void)hipStreamDestroy(c.tail);
     for (int p = 0; p < 2; ++p) {
         if (c.ev_scan[p]) (void)hipEventDestroy(c.ev_scan[p]);
@@ -280,7 +285,7 @@ extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     else if (s == "tail_stop") idx->tail_stop = (int)v;
     else if (s == "epi" || s == "fused_epi") idx->epi = (int)v != 0;   // selection form of the 64-query scan (default variant and fused launch): 1 = positions inside the scores, 0 = compare / select
     else if (s == "profile_legacy") idx->profile_legacy = (int)v != 0;   // time scans with hipEventRecord around the launch (round 1) instead of dispatch-attached events
-    else if (s == "tail_first") idx->tail_first = (int)v != 0;   // fused launch: tail workgroups take the first block ids
+    else if (s == "use_hint") idx->use_hint = (int)v != 0;   // 0: rq_search_hint_next_device is ignored (A/B of the folded query preparation)
     else if (s == "poison_cand") idx->poison_cand = (int)v;   // test hook: candidate lists are filled with 0xff..ff keys before every tail
     else return set_err(RQ_EINVAL, "unknown option '%s'", name);
     return RQ_OK;
@@ -309,6 +314,7 @@ extern "C" double rq_get_option(const rq_index* idx, const char* name) {
     if (s == "profile_stride") return idx->profile_stride;
     if (s == "cu_count") return idx->cu_count;
     if (s == "max_row_norm") return idx->max_row_norm;
+    if (s == "hints_used") return (double)idx->hints_used;   // searches that found their queries prepared by the launch before them
     if (s == "max_sub_rel") return idx->max_sub_rel;   // largest share of a row's norm that sits in fp16-subnormal elements
     if (s == "max_sub_abs") return idx->max_sub_abs;
     if (s == "eps_cosine") return scan_eps(idx, RQ_METRIC_COSINE);
@@ -393,6 +399,7 @@ static int flush_tails(rq_index* idx, hipStream_t s) {
     auto it = idx->ctx.find(s);
     if (it == idx->ctx.end()) return RQ_OK;
     StreamCtx& c = it->second;
+    c.hint_q = nullptr;   // a flush ends the loop the hint belonged to (queries already prepared stay usable)
     if (c.fused_pending) {
         c.fused_pending = false;
         if (int r = poison_cand(idx, c.fused_tail, c.fused_B, s)) return r;
@@ -480,9 +487,15 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     // fused mode: one scan launch per call (<= 64 queries), which carries the tail of the previous call
     const bool fused = fast && may_defer && idx->pipeline == 2 && bpad == 64;
     const int qb0 = pass_q[0];
-    int par = 0;
+    int par = 0, slot = -1;
     if (fused) {
+        slot = (int)(cx.calls % 3);
         par = (int)(cx.calls++ & 1);
+        for (int p = 0; p < 3; ++p) {
+            if (!cx.ring_qh[p]) HIPCHK(hipMalloc((void**)&cx.ring_qh[p], (size_t)64 * RQ_DPAD * sizeof(_Float16)));
+            if (!cx.ring_q32[p]) HIPCHK(hipMalloc((void**)&cx.ring_q32[p], (size_t)64 * RQ_DPAD * sizeof(float)));
+            if (!cx.ring_qn[p]) HIPCHK(hipMalloc((void**)&cx.ring_qn[p], (size_t)64 * sizeof(double)));
+        }
     } else if (piped) {
         if (cx.fused_pending) { if (int r = flush_tails(idx, s)) return r; }
         if (!cx.tail) {
@@ -499,6 +512,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     } else {
         if (int r = flush_tails(idx, s)) return r;   // order after anything still on the tail stream
     }
+    if (!fused) cx.hint_q = nullptr;   // a hint is for the next FUSED call of the stream only
     Workspace& w = cx.w[par];
     if (int r = ensure_ws(w, bpad, exact ? 64 : stride, exact ? 1 : m, (size_t)B * (size_t)ncand)) return r;
     const float* scale = idx->inv_norm;
@@ -512,7 +526,21 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
         w.counters_zero = true;
     }
     // unit-norm fp16 query fragments for the scan (+ padded fp32 queries / fp64 norms for the generic tail)
-    HIPCHK(rq_prep_queries_launch(d_q, idx->dim, B, bpad, w.qh, w.q32, w.qn, s));
+    _Float16* const qh = fused ? cx.ring_qh[slot] : w.qh;
+    float* const q32 = fused ? cx.ring_q32[slot] : w.q32;
+    double* const qn = fused ? cx.ring_qn[slot] : w.qn;
+    // ... unless the previous launch of this stream has already prepared exactly these queries (rq_search_hint_next_device)
+    const bool prepared = fused && cx.prepped_q == d_q && cx.prepped_B == B && cx.prepped_slot == slot;
+    cx.prepped_q = nullptr;
+    if (prepared) idx->hints_used++;
+    if (!prepared) HIPCHK(rq_prep_queries_launch(d_q, idx->dim, B, bpad, qh, q32, qn, s));
+    // the queries announced for the NEXT call are prepared by extra workgroups of this call's fused launch
+    RqPrepArgs pa{};
+    if (fused && cx.hint_q) {
+        const int nslot = (slot + 1) % 3;
+        pa.q = cx.hint_q; pa.dim = idx->dim; pa.B = cx.hint_B; pa.nslots = 64;
+        pa.qh = cx.ring_qh[nslot]; pa.q32pad = cx.ring_q32[nslot]; pa.qnorm64 = cx.ring_qn[nslot];
+    }
     // one scan grid for every pass of the call (the tail reads nwg partition maxima per query): the widest pass decides
     const int wg_cu = qb0 > 64 ? 1 : idx->wg_per_cu;   // every pass of more than 64 queries runs one 512-thread workgroup per CU
     const int grid = (int)std::min<int64_t>(std::min<int64_t>(nquads, RQ_WGMAX_STRIDE), (int64_t)idx->cu_count * wg_cu);
@@ -525,7 +553,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             RqScanArgs a;
             a.x = idx->x;
             a.row_scale = scale;
-            a.qh = w.qh + (size_t)q0 * RQ_DPAD;
+            a.qh = qh + (size_t)q0 * RQ_DPAD;
             a.bins = w.bins + (size_t)q0 * w.bins_stride;
             a.bins_stride = w.bins_stride;
             a.n_rows = idx->n;
@@ -549,16 +577,24 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
                 cx.fused_pending = false;
                 if (int r = poison_cand(idx, cx.fused_tail, cx.fused_B, s)) return r;
                 if (idx->tail_stop == 9) {   // development: fused kernel without its tail workgroups, tail launched after it
-                    HIPCHK(rq_scan_tail_launch(a, cx.fused_tail, 0, nt, grid, idx->epi, idx->tail_first != 0, s, e0, e1));
+                    HIPCHK(rq_scan_tail_launch(a, cx.fused_tail, 0, pa, nt, grid, idx->epi, s, e0, e1));
                     RqTailArgs t9 = cx.fused_tail; t9.stop_after = 0;
                     HIPCHK(rq_tail_launch(t9, cx.fused_B, s));
                 } else
-                HIPCHK(rq_scan_tail_launch(a, cx.fused_tail, cx.fused_B, nt, grid, idx->epi, idx->tail_first != 0, s, e0, e1));
+                HIPCHK(rq_scan_tail_launch(a, cx.fused_tail, cx.fused_B, pa, nt, grid, idx->epi, s, e0, e1));
+            } else if (fused && pa.nslots) {   // first call of a loop: no tail to carry yet, but queries to prepare
+                RqTailArgs none{};
+                none.nbins = nbins; none.m = none.k = 1;
+                HIPCHK(rq_scan_tail_launch(a, none, 0, pa, nt, grid, idx->epi, s, e0, e1));
             } else if (fused) HIPCHK(rq_scan_launch(a, 3, 1, 2, 4, nt, grid, idx->epi, s, e0, e1));
             else if (qb == 256) HIPCHK(rq_scan_wide_launch(a, idx->wide256, 256, nt, grid, s, e0, e1));
             else if (qb == 128 && idx->wide_batch == 2) HIPCHK(rq_scan_launch(a, 3, 4, 1, 8, nt, grid, 0, s, e0, e1));   // round 1's 8-wave pass
             else if (qb == 128) HIPCHK(rq_scan_wide_launch(a, idx->wide128, 128, nt, grid, s, e0, e1));
             else HIPCHK(rq_scan_launch(a, idx->ring, idx->prefetch, idx->kstage, 4, nt, grid, idx->epi, s, e0, e1));
+            if (fused && pa.nslots) {
+                cx.prepped_q = cx.hint_q; cx.prepped_B = cx.hint_B; cx.prepped_slot = (slot + 1) % 3;
+                cx.hint_q = nullptr;
+            }
             if (prof) { if (idx->profile_legacy) HIPCHK(hipEventRecord(idx->events[idx->ev_used].second, s)); idx->ev_used++; }
         }
         if (fast) {
@@ -583,7 +619,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             if (fused) {
                 // the tail runs with the NEXT scan launch (or at the flush): it reads the workspace's own copy of the
                 // queries, so the caller's buffer is free as soon as this call's work has run
-                ta.q = w.q32; ta.dim = RQ_DPAD;
+                ta.q = q32; ta.dim = RQ_DPAD;
                 cx.fused_tail = ta; cx.fused_B = B; cx.fused_pending = true;
                 return RQ_OK;
             }
@@ -637,6 +673,21 @@ extern "C" int rq_search_device(rq_index* idx, const float* d_queries, int B, in
     idx->t.searches++;
     idx->t.queries += B;
     return run_pipeline(idx, d_queries, B, k, metric, nb_default(idx, k), d_scores, d_rows, d_keys, d_status, (hipStream_t)stream, true);
+}
+
+// The queries of the NEXT rq_search_device call on `stream` ("pipeline" = 2 loops): the call made right after this one
+// prepares them with 64 extra workgroups of its own launch, and the call after that -- if it is given exactly d_next_queries
+// and B -- skips its preparation launch.  Advisory: anything else simply prepares its queries itself.
+extern "C" int rq_search_hint_next_device(rq_index* idx, const float* d_next_queries, int B, void* stream) {
+    if (!idx) return set_err(RQ_EINVAL, "null index");
+    if (!idx->shards.empty()) return set_err(RQ_EUNSUPPORTED, "device-pointer searches on a multi-device index: use rq_search (host buffers), or one index per device");
+    if (B < 0 || B > 65535) return set_err(RQ_EINVAL, "B %d outside 0..65535", B);
+    if (idx->ctx.find((hipStream_t)stream) == idx->ctx.end() && idx->ctx.size() >= RQ_MAX_STREAM_CTX) return RQ_OK;   // dropped: advisory
+    StreamCtx& c = idx->ctx[(hipStream_t)stream];
+    const bool usable = d_next_queries && B >= 1 && B <= 64 && idx->use_hint && idx->pipeline == 2;
+    c.hint_q = usable ? d_next_queries : nullptr;
+    c.hint_B = usable ? B : 0;
+    return RQ_OK;
 }
 
 extern "C" int rq_search_flush_device(rq_index* idx, void* stream) {

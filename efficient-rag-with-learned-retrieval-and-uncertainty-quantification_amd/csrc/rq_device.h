@@ -110,6 +110,34 @@ __device__ __forceinline__ double rq_wave_sum(double v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;   // identical in every lane (xor butterfly)
 }
+// Query preparation of one query slot by one 256-thread workgroup (thread t owns elements t, 256 + t, 512 + t):
+// fp64 norm, qh = fp16(q / |q| * 2^12) (the factor: rq_select.hip), zero padded raw copy, slots >= B all zero.
+// `part` = 4 doubles of LDS.
+template <class PrepArgs>
+__device__ __forceinline__ void rq_prep_body(const PrepArgs& a, const int qi, double* part) {
+    const int tid = threadIdx.x;
+    float v[3];
+    double acc = 0.0;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const int i = p * 256 + tid;
+        v[p] = (qi < a.B && i < a.dim) ? a.q[(size_t)qi * a.dim + i] : 0.f;
+        acc += (double)v[p] * (double)v[p];
+    }
+    acc = rq_wave_sum(acc);
+    if ((tid & 63) == 0) part[tid >> 6] = acc;
+    __syncthreads();
+    const double nrm = sqrt((part[0] + part[1]) + (part[2] + part[3]));
+    if (tid == 0 && qi < a.B) a.qnorm64[qi] = nrm;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const int i = p * 256 + tid;
+        const float f = nrm > 0.0 ? (float)((double)v[p] / nrm) * RQ_QSCALE : 0.f;
+        a.qh[(size_t)qi * RQ_DPAD + i] = (_Float16)f;
+        a.q32pad[(size_t)qi * RQ_DPAD + i] = v[p];
+    }
+}
+
 __device__ __forceinline__ float rq_sanitize(float f) { return (f != f) ? -__builtin_huge_valf() : f; }
 __device__ __forceinline__ uint64_t rq_wave_max_u64(uint64_t v) {
 #pragma unroll

@@ -72,6 +72,16 @@ struct StreamCtx {
     bool fused_pending = false;
     RqTailArgs fused_tail;
     int fused_B = 0;
+    // "pipeline" = 2 keeps the prepared queries of three consecutive calls apart (slot = call number mod 3): call i scans
+    // slot i, the tail of call i - 1 that rides with it reads slot i - 1, and the extra workgroups of the same launch prepare
+    // the hinted queries of call i + 1 into slot i + 1 (rq_search_hint_next_device)
+    _Float16* ring_qh[3] = {nullptr, nullptr, nullptr};
+    float* ring_q32[3] = {nullptr, nullptr, nullptr};
+    double* ring_qn[3] = {nullptr, nullptr, nullptr};
+    const float* hint_q = nullptr;      // queries announced for the next fused call, not yet prepared
+    int hint_B = 0;
+    const float* prepped_q = nullptr;   // queries a launch has already prepared ...
+    int prepped_B = 0, prepped_slot = -1;   // ... and the slot they are in
 };
 
 // Default scan variant: half-row stages (kstage 2), ring of 3, one LDS fragment ahead (prefetch 1, <= 168 VGPRs),
@@ -88,9 +98,10 @@ struct rq_index {
     double* d_maxnorm = nullptr;   // device: bits of the running maxima {row norm, relative, absolute fp16-subnormal mass of a row}
     double max_row_norm = 0.0, max_sub_rel = 0.0, max_sub_abs = 0.0;
     unsigned long long* dbg_stamps = nullptr;   // development (rq_debug_stamps)
+    int64_t hints_used = 0;        // rq_search_hint_next_device: searches that skipped their preparation launch
     uint64_t scan_seq = 0;         // scan launches seen while profile = 1 (every profile_stride-th one is timed)
     // options
-    int ring = 3, prefetch = 1, kstage = 2, wide_batch = 1, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, profile_stride = 1, scan_nostore = 0, fast_tail = 1, pipeline = 0, tail_stop = 0, poison_cand = 0, wide128 = 0, wide256 = 11, epi = 1, tail_first = 0, profile_legacy = 0;
+    int ring = 3, prefetch = 1, kstage = 2, wide_batch = 1, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, profile_stride = 1, scan_nostore = 0, fast_tail = 1, pipeline = 0, tail_stop = 0, poison_cand = 0, wide128 = 0, wide256 = 11, epi = 1, use_hint = 1, profile_legacy = 0;
     double eps = -1.0;
     std::map<hipStream_t, StreamCtx> ctx;
     hipStream_t own_stream = nullptr;

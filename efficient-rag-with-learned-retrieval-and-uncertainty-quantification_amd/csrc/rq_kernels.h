@@ -36,7 +36,14 @@ hipError_t rq_rownorm_launch(const void* x, int64_t row_begin, int64_t row_end, 
 hipError_t rq_convert_f32_launch(const float* src, int dim, int64_t n, int normalize, void* dst_rows_f16, hipStream_t stream);
 hipError_t rq_pad_f16_launch(const void* src, int dim, int64_t n, void* dst_rows_f16, hipStream_t stream);
 
-// Query preparation: qnorm64[q] = ||q|| (fp64); qh = fp16(q/||q||) padded to 768, slots >= B zero.
+// Query preparation: qnorm64[q] = ||q|| (fp64); qh = fp16(q / ||q|| * 2^12) padded to 768, slots >= B zero.
+// One 256-thread workgroup per query slot (rq_device.h rq_prep_body); run by rq_prep_queries_kernel or, for the NEXT batch
+// of a throughput loop, by extra workgroups of the fused scan + tail launch (include/rq.h rq_search_hint_next_device).
+struct RqPrepArgs {
+    const float* q; int dim; int B;      // raw fp32 queries [B][dim]
+    _Float16* qh; float* q32pad; double* qnorm64;
+    int nslots;                          // workgroups = query slots written (padded batch size), 0 = none
+};
 hipError_t rq_prep_queries_launch(const float* q, int dim, int B, int Bpad, _Float16* qh, float* q32pad, double* qnorm64,
                                   hipStream_t stream);
 
@@ -101,8 +108,9 @@ struct RqTailArgs {
     unsigned long long* dbg;                       // development: per-workgroup (start, end) wall-clock stamps of the fused launch, or null
     int stop_after;                                // development: 0 = full kernel, 1..4 = return after phase A..D
 };
-// workgroups [0, scan_grid) run the scan `sa`, the rest the tail `ta` of an EARLIER batch 
-hipError_t rq_scan_tail_launch(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, bool nt, int scan_grid, int epi, bool tail_first, hipStream_t stream,
+// workgroups [0, scan_grid) run the scan `sa`, the next ones the tail `ta` of an EARLIER batch, the last pa.nslots the query
+// preparation `pa` of a LATER batch
+hipError_t rq_scan_tail_launch(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, const RqPrepArgs& pa, bool nt, int scan_grid, int epi, hipStream_t stream,
                                hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 hipError_t rq_tail_launch(const RqTailArgs& a, int B, hipStream_t stream);
 // chunk size rule shared by both launchers: 512-bin chunks while that keeps the grid around a thousand workgroups

@@ -261,20 +261,21 @@ __global__ __launch_bounds__(64 * QW, OCC) void rq_scan_kernel(RqScanArgs a) {
 // 53 760 B of LDS, <= 168 VGPRs), so a CU holds 2 scan workgroups + 1 tail workgroup (3 x 53 760 B <= 160 KB; the
 // tail's 16 KB are carved from the ring).
 template <bool NT, int NV, int EPI>
-__global__ __launch_bounds__(256, 3) void rq_scan_tail_kernel(RqScanArgs sa, RqTailArgs ta, int scan_grid, int tail_chunks) {
+__global__ __launch_bounds__(256, 3) void rq_scan_tail_kernel(RqScanArgs sa, RqTailArgs ta, RqPrepArgs pa, int scan_grid, int tail_chunks) {
     unsigned long long t0 = 0;
     if (ta.dbg) t0 = wall_clock64();
-    // tail_chunks < 0: the tail workgroups take the FIRST block ids (dispatched before the scan workgroups), else the last
-    const int ntail = (int)gridDim.x - scan_grid;
-    const bool tail_first = tail_chunks < 0;
-    const int tc = tail_first ? -tail_chunks : tail_chunks;
+    // block ids: [0, scan_grid) scan THIS batch | the tail workgroups of the PREVIOUS batch | pa.nslots workgroups that prepare
+    // the queries of the NEXT batch (rq_search_hint_next_device), so that the next call needs no preparation launch
     const int bid = (int)blockIdx.x;
-    const int sb = tail_first ? bid - ntail : bid;          // scan workgroup index, valid in [0, scan_grid)
-    if (sb >= 0 && sb < scan_grid) {
-        rq_scan_body<3, NT, 1, 2, 4, EPI>(sa, sb, scan_grid);
+    const int nprep = pa.nslots;
+    const int ntail = (int)gridDim.x - scan_grid - nprep;
+    if (bid < scan_grid) {
+        rq_scan_body<3, NT, 1, 2, 4, EPI>(sa, bid, scan_grid);
+    } else if (bid < scan_grid + ntail) {
+        const int t = bid - scan_grid;
+        rq_tail_body<NV>(ta, t % tail_chunks, t / tail_chunks, tail_chunks, *reinterpret_cast<RqTailLds*>(rq_smem));
     } else {
-        const int t = tail_first ? bid : bid - scan_grid;
-        rq_tail_body<NV>(ta, t % tc, t / tc, tc, *reinterpret_cast<RqTailLds*>(rq_smem));
+        rq_prep_body(pa, bid - scan_grid - ntail, reinterpret_cast<double*>(rq_smem));
     }
     if (ta.dbg && threadIdx.x == 0) {
         ta.dbg[4 * blockIdx.x] = t0; ta.dbg[4 * blockIdx.x + 1] = wall_clock64();
@@ -327,7 +328,7 @@ hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int ks, int qw, bo
 
 // ---- fused scan(batch i) + tail(batch i-1) -------------------------------------------------------------------
 template <bool NT, int NV, int EPI>
-static hipError_t rq_scan_tail_launch_t(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, int scan_grid, bool tail_first, hipStream_t stream,
+static hipError_t rq_scan_tail_launch_t(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, const RqPrepArgs& pa, int scan_grid, hipStream_t stream,
                                         hipEvent_t e0, hipEvent_t e1) {
     constexpr size_t lds = rq_scan_lds_bytes(3, 2, 4);
     static_assert(sizeof(RqTailLds) <= lds, "tail LDS must fit in the scan's LDS");
@@ -343,15 +344,14 @@ static hipError_t rq_scan_tail_launch_t(const RqScanArgs& sa, const RqTailArgs& 
         if (e != hipSuccess) return e;
         attr_done |= 1ull << (dev & 63);
     }
-    const int tc = tail_first ? -(int)chunks : (int)chunks;
-    if (e0 && e1) hipExtLaunchKernelGGL((rq_scan_tail_kernel<NT, NV, EPI>), dim3((unsigned)(scan_grid + chunks * tail_B)), dim3(256), (uint32_t)lds, stream, e0, e1, 0,
-                                        sa, ta, scan_grid, tc);
-    else hipLaunchKernelGGL((rq_scan_tail_kernel<NT, NV, EPI>), dim3((unsigned)(scan_grid + chunks * tail_B)), dim3(256), lds, stream, sa, ta, scan_grid, tc);
+    const unsigned grid = (unsigned)(scan_grid + chunks * tail_B + pa.nslots);
+    if (e0 && e1) hipExtLaunchKernelGGL((rq_scan_tail_kernel<NT, NV, EPI>), dim3(grid), dim3(256), (uint32_t)lds, stream, e0, e1, 0, sa, ta, pa, scan_grid, (int)chunks);
+    else hipLaunchKernelGGL((rq_scan_tail_kernel<NT, NV, EPI>), dim3(grid), dim3(256), lds, stream, sa, ta, pa, scan_grid, (int)chunks);
     return hipGetLastError();
 }
 
 template <int EPI>
-static hipError_t rq_scan_tail_launch_e(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, bool nt, int scan_grid, bool tail_first, hipStream_t stream,
+static hipError_t rq_scan_tail_launch_e(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, const RqPrepArgs& pa, bool nt, int scan_grid, hipStream_t stream,
                                         hipEvent_t e0, hipEvent_t e1) {
     if (scan_grid <= 0 || tail_B < 0) return hipErrorInvalidValue;   // tail_B = 0: development (the fused kernel without tail workgroups)
     if (ta.m < 1 || ta.m > RQ_FAST_MAX_M || ta.k < 1 || ta.k > RQ_FAST_MAX_K) return hipErrorInvalidValue;
@@ -360,17 +360,18 @@ static hipError_t rq_scan_tail_launch_e(const RqScanArgs& sa, const RqTailArgs& 
     // 2048 bins 252.4 us).  The stand-alone launch (rq_tail_launch) prefers more, smaller ones: lower latency.
     const auto wgs = [&](int nv) { return ((ta.nbins + 512 * nv - 1) / (512 * nv)) * tail_B; };
     const int nv = wgs(1) <= 384 ? 1 : (wgs(4) <= 384 ? 4 : 8);
-    if (nt) return nv == 1 ? rq_scan_tail_launch_t<true, 1, EPI>(sa, ta, tail_B, scan_grid, tail_first, stream, e0, e1)
-                 : nv == 4 ? rq_scan_tail_launch_t<true, 4, EPI>(sa, ta, tail_B, scan_grid, tail_first, stream, e0, e1)
-                           : rq_scan_tail_launch_t<true, 8, EPI>(sa, ta, tail_B, scan_grid, tail_first, stream, e0, e1);
-    return nv == 1 ? rq_scan_tail_launch_t<false, 1, EPI>(sa, ta, tail_B, scan_grid, tail_first, stream, e0, e1)
-         : nv == 4 ? rq_scan_tail_launch_t<false, 4, EPI>(sa, ta, tail_B, scan_grid, tail_first, stream, e0, e1)
-                   : rq_scan_tail_launch_t<false, 8, EPI>(sa, ta, tail_B, scan_grid, tail_first, stream, e0, e1);
+    if (nt) return nv == 1 ? rq_scan_tail_launch_t<true, 1, EPI>(sa, ta, tail_B, pa, scan_grid, stream, e0, e1)
+                 : nv == 4 ? rq_scan_tail_launch_t<true, 4, EPI>(sa, ta, tail_B, pa, scan_grid, stream, e0, e1)
+                           : rq_scan_tail_launch_t<true, 8, EPI>(sa, ta, tail_B, pa, scan_grid, stream, e0, e1);
+    return nv == 1 ? rq_scan_tail_launch_t<false, 1, EPI>(sa, ta, tail_B, pa, scan_grid, stream, e0, e1)
+         : nv == 4 ? rq_scan_tail_launch_t<false, 4, EPI>(sa, ta, tail_B, pa, scan_grid, stream, e0, e1)
+                   : rq_scan_tail_launch_t<false, 8, EPI>(sa, ta, tail_B, pa, scan_grid, stream, e0, e1);
 }
 
 // epi: selection form of the scan workgroups (0 = compare / select, 1 = positions inside the scores)
-hipError_t rq_scan_tail_launch(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, bool nt, int scan_grid, int epi, bool tail_first, hipStream_t stream,
+hipError_t rq_scan_tail_launch(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, const RqPrepArgs& pa, bool nt, int scan_grid, int epi, hipStream_t stream,
                                hipEvent_t e0, hipEvent_t e1) {
-    return epi ? rq_scan_tail_launch_e<1>(sa, ta, tail_B, nt, scan_grid, tail_first, stream, e0, e1)
-               : rq_scan_tail_launch_e<0>(sa, ta, tail_B, nt, scan_grid, tail_first, stream, e0, e1);
+    if (pa.nslots < 0 || pa.nslots > 64) return hipErrorInvalidValue;
+    return epi ? rq_scan_tail_launch_e<1>(sa, ta, tail_B, pa, nt, scan_grid, stream, e0, e1)
+               : rq_scan_tail_launch_e<0>(sa, ta, tail_B, pa, nt, scan_grid, stream, e0, e1);
 }

@@ -150,33 +150,15 @@ hipError_t rq_pad_f16_launch(const void* src, int dim, int64_t n, void* dst, hip
 // qh = fp16(q / |q| * 2^12): |element| <= 4096, and an element is flushed by the matrix cores (fp16 subnormal) only below
 // 2^-26 of the unit query -- at most sqrt(768) * 2^-26 = 4e-7 of score error, against 1.7e-3 without the scaling.
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rq_prep_queries_kernel(const float* q, int dim, int B, _Float16* qh, float* q32pad, double* qnorm64) {
+__global__ __launch_bounds__(256) void rq_prep_queries_kernel(RqPrepArgs a) {
     __shared__ double part[4];
-    const int qi = blockIdx.x, tid = threadIdx.x;
-    float v[3];
-    double acc = 0.0;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        const int i = p * 256 + tid;
-        v[p] = (qi < B && i < dim) ? q[(size_t)qi * dim + i] : 0.f;
-        acc += (double)v[p] * (double)v[p];
-    }
-    acc = rq_wave_sum(acc);
-    if ((tid & 63) == 0) part[tid >> 6] = acc;
-    __syncthreads();
-    const double nrm = sqrt((part[0] + part[1]) + (part[2] + part[3]));
-    if (tid == 0 && qi < B) qnorm64[qi] = nrm;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        const int i = p * 256 + tid;
-        const float f = nrm > 0.0 ? (float)((double)v[p] / nrm) * RQ_QSCALE : 0.f;
-        qh[(size_t)qi * RQ_DPAD + i] = (_Float16)f;
-        q32pad[(size_t)qi * RQ_DPAD + i] = v[p];
-    }
+    rq_prep_body(a, (int)blockIdx.x, part);
 }
 hipError_t rq_prep_queries_launch(const float* q, int dim, int B, int Bpad, _Float16* qh, float* q32pad, double* qnorm64,
                                   hipStream_t stream) {
-    hipLaunchKernelGGL(rq_prep_queries_kernel, dim3(Bpad), dim3(256), 0, stream, q, dim, B, qh, q32pad, qnorm64);
+    RqPrepArgs a;
+    a.q = q; a.dim = dim; a.B = B; a.qh = qh; a.q32pad = q32pad; a.qnorm64 = qnorm64; a.nslots = Bpad;
+    hipLaunchKernelGGL(rq_prep_queries_kernel, dim3(Bpad), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -97,6 +97,14 @@ int rq_search_device(rq_index* idx, const float* d_queries, int B, int k, int me
  * (rq_search_fixup_device implies it); output buffers must stay valid until then.  Mode 1 also reads d_queries
  * until then, mode 2 keeps its own copy. */
 int rq_search_flush_device(rq_index* idx, void* stream);
+/* "pipeline" = 2 loops that know their next batch: announce the queries of the NEXT rq_search_device call on `stream`
+ * before making the current one.  The current call's launch then prepares them (norms, unit-norm fp16 fragments) with 64
+ * extra workgroups, and the next call -- when it is given exactly d_next_queries and B -- needs no preparation launch of its
+ * own (measured: one 5 us kernel + a launch boundary per batch).  d_next_queries must hold its final contents when the
+ * current call is made and stay unchanged until the call that searches it.  Advisory: a hint that cannot be used (more than
+ * 64 queries, another pipeline mode, a different pointer / B at the next call, a flush in between) is dropped and the
+ * next call prepares its queries itself; results never depend on it.  B = 0 or NULL withdraws a pending hint. */
+int rq_search_hint_next_device(rq_index* idx, const float* d_next_queries, int B, void* stream);
 /* The library keeps one search workspace per caller stream (about 11 MB at 1M rows and 64 queries).  Call this before a
  * stream that has been used for searches is destroyed, or when it will not be used again: waits for the device, runs
  * any deferred tail, frees the stream's workspace.  (Beyond 8 streams the library drops idle workspaces by itself.) */
@@ -119,8 +127,9 @@ int rq_merge_keys_device(const uint64_t* d_keys_in, int n_per_query, int B, int 
  * "pipeline" (see rq_search_flush_device), "wide_batch" (calls of more than 64 queries: 0 = passes of 64 only, 1 = passes of
  * 256 / 128 / 64, 3 = 128 / 64, 2 = round 1's 8-wave 128-query pass), "wide128" / "wide256" (variant of csrc/rq_scan_wide.hip),
  * "epi" (selection form of the 64-query scan: 1 = row positions inside the scores, 0 = compare / select),
+ * "use_hint" (0: rq_search_hint_next_device is ignored),
  * "poison_cand" (test hook: candidate lists are filled with 0xff..ff keys before every tail).
- * Read-only: "max_row_norm", "max_sub_rel" / "max_sub_abs" (largest share of a stored row that sits in fp16-subnormal elements,
+ * Read-only: "hints_used" (searches that found their queries prepared, see rq_search_hint_next_device), "max_row_norm", "max_sub_rel" / "max_sub_abs" (largest share of a stored row that sits in fp16-subnormal elements,
  * which the matrix cores flush), "eps_cosine" / "eps_ip" (the certificate's bound including that term). */
 int rq_set_option(rq_index* idx, const char* name, double value);
 double rq_get_option(const rq_index* idx, const char* name);

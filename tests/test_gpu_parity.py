@@ -291,6 +291,77 @@ def test_deferred_tails_over_many_batches(mode):
     idx.close()
 
 
+def test_next_batch_hint_never_changes_results():
+    """rq_search_hint_next_device (pipeline = 2): the queries announced for the next call are prepared by extra workgroups
+    of the current call's fused launch (slot ring of three, csrc/rq_index.h StreamCtx).  A train of calls with hints that
+    match, hints for another buffer, another B, a withdrawn hint, a hint followed by a wide / flushed call, ragged batches
+    (slots >= B must be zero) and a zero query: every batch exact, and exactly the matching hints are counted as used."""
+    import torch
+    x16 = orc.synthetic_corpus(70_000, 768, seed=78)
+    x16[900:910] = x16[5]
+    idx = nat.NativeIndex(768, 0)
+    idx.add_f16(x16)
+    idx.set_option("pipeline", 2)
+    idx.set_option("poison_cand", 1)
+    idx.set_option("profile", 1)              # counts the scan launches: one per call, with or without a hint
+    dev = torch.device("cuda:0")
+    st = torch.cuda.Stream(device=dev)
+    # (B, k, what is announced before the call: "next" = the next call's buffer and B, "other" = a different buffer,
+    #  "wrongB" = right buffer, B - 1, "none", "withdraw" = next then NULL), flush after the call?
+    plan = [(64, 10, "next", False), (64, 10, "next", False), (17, 10, "next", False), (64, 20, "other", False),
+            (64, 10, "wrongB", False), (64, 10, "next", False), (64, 100, "withdraw", False), (64, 10, "next", True),
+            (64, 10, "next", False), (100, 10, "next", False), (64, 10, "next", False), (1, 1, "next", False), (64, 5, "none", False)]
+    qs = [orc.synthetic_queries(B, 768, seed=1300 + i) for i, (B, k, h, f) in enumerate(plan)]
+    qs[2][3] = 0
+    qs[5][0] = x16[5].astype(np.float32)
+    dq = [torch.from_numpy(q).to(dev) for q in qs]
+    other = torch.from_numpy(orc.synthetic_queries(64, 768, seed=5)).to(dev)
+    outs = []
+    with torch.cuda.stream(st):
+        for i, (B, k, hint, flush_after) in enumerate(plan):
+            nxt = dq[i + 1] if i + 1 < len(plan) else other
+            nB = plan[i + 1][0] if i + 1 < len(plan) else 64
+            if hint == "next":
+                idx.search_hint_next_device(nxt, nB, st.cuda_stream)
+            elif hint == "other":
+                idx.search_hint_next_device(other, 64, st.cuda_stream)
+            elif hint == "wrongB":
+                idx.search_hint_next_device(nxt, nB - 1, st.cuda_stream)
+            elif hint == "withdraw":
+                idx.search_hint_next_device(nxt, nB, st.cuda_stream)
+                idx.search_hint_next_device(None, 0, st.cuda_stream)
+            sc = torch.full((B, k), -7.0, device=dev); rw = torch.full((B, k), -7, device=dev, dtype=torch.int64)
+            stt = torch.full((B,), 9, device=dev, dtype=torch.int32)
+            idx.search_device(dq[i], B, k, 0, sc, rw, None, stt, st.cuda_stream)
+            if flush_after:
+                idx.search_flush_device(st.cuda_stream)
+            outs.append((sc, rw, stt))
+        idx.search_flush_device(st.cuda_stream)
+    st.synchronize()
+    for i, ((B, k, hint, f), q, (sc, rw, stt)) in enumerate(zip(plan, qs, outs)):
+        es, er = orc.dense_topk(q, x16, k)
+        assert int(stt.abs().sum()) == 0, f"call {i}: status {stt.cpu().tolist()}"
+        assert np.array_equal(rw.cpu().numpy(), er), f"call {i}"
+        assert float(np.abs(sc.cpu().numpy() - es).max()) <= SCORE_TOL
+    # used: calls 1, 2, 3 (announced by 0, 1, 2), 6 (by 5), 8 (by 7: prepared before the flush, still valid),
+    # 11 and 12 (by 10, 11).  Not: 4 (other buffer), 5 (wrong B), 7 (withdrawn), 9 (100 queries: not a fused call), 10 (announced by
+    # a call that was not fused)
+    assert int(idx.get_option("hints_used")) == 7
+    assert idx.timing()["scan_launches"] == len(plan)
+    idx.set_option("use_hint", 0)
+    before = int(idx.get_option("hints_used"))
+    with torch.cuda.stream(st):
+        for i in (0, 1):
+            idx.search_hint_next_device(dq[i + 1], 64, st.cuda_stream)
+            sc, rw, stt = outs[i]
+            idx.search_device(dq[i], 64, 10, 0, sc, rw, None, stt, st.cuda_stream)
+        idx.search_flush_device(st.cuda_stream)
+    st.synchronize()
+    assert int(idx.get_option("hints_used")) == before
+    assert idx.timing()["scan_launches"] == len(plan) + 2
+    idx.close()
+
+
 def test_two_streams_with_fused_tails_like_the_multi_gpu_bench():
     """bench.py at N > 1: two caller streams alternate, each with deferred (fused) tails, keys of 16 batches collected
     in one buffer before they are read.  Every batch must be exact after the flushes."""
@@ -553,16 +624,19 @@ def test_fused_headline_instantiation_matches_oracle(n, expect_nv):
     qs[1][: len(planted)] = np.stack([idx.get_rows_f16(p, 1)[0] for p in planted]).astype(np.float32)
     outs = []
     with torch.cuda.stream(st):
-        for (k, m), q in zip(plan, qs):
-            dq = torch.from_numpy(q).to(dev)
+        dqs = [torch.from_numpy(q).to(dev) for q in qs]
+        for i, ((k, m), dq) in enumerate(zip(plan, dqs)):
             sc = torch.full((64, k), -7.0, device=dev); rw = torch.full((64, k), -7, device=dev, dtype=torch.int64)
             stt = torch.full((64,), 9, device=dev, dtype=torch.int32)
+            if i + 1 < len(plan) and i != 3:      # as bench.py does: the next batch's queries are prepared inside this launch
+                idx.search_hint_next_device(dqs[i + 1], 64, st.cuda_stream)
             idx.search_device(dq, 64, k, m, sc, rw, None, stt, st.cuda_stream)
             outs.append((dq, sc, rw, stt))
         idx.search_flush_device(st.cuda_stream)
     st.synchronize()
     t = idx.timing()
     assert t["widened"] == 0 and t["exact_scans"] == 0
+    assert int(idx.get_option("hints_used")) == len(plan) - 2
     x16 = idx.get_rows_f16(0, n)
     cos = orc.exact_scores(np.concatenate([q for q, (k, m) in zip(qs, plan) if m == 0], 0), x16, 0)
     ip = orc.exact_scores(np.concatenate([q for q, (k, m) in zip(qs, plan) if m == 1], 0), x16, 1)
