@@ -46,6 +46,13 @@ extern "C" const char* rq_version(void) { return "rq-hip 0.1 (gfx950)"; }
 static int flush_all(rq_index* idx);   // launches every tail still waiting for a scan ("pipeline" = 2)
 static const size_t RQ_MAX_STREAM_CTX = 8;
 
+static void drop_x8(rq_index* idx) {
+    void* p[] = {idx->x8, idx->scale8_cos, idx->scale8_ip};
+    for (void* q : p) if (q) (void)hipFree(q);
+    idx->x8 = nullptr; idx->scale8_cos = nullptr; idx->scale8_ip = nullptr;
+    idx->x8_valid = 0; idx->max_e8 = 0.0;
+}
+
 static int grow(rq_index* idx, int64_t want_rows) {
     if (want_rows <= idx->cap) return RQ_OK;
     int64_t cap = std::max<int64_t>(idx->cap * 2, 4096);
@@ -78,6 +85,7 @@ static int grow(rq_index* idx, int64_t want_rows) {
     if (idx->rownorm64) (void)hipFree(idx->rownorm64);
     if (idx->inv_norm) (void)hipFree(idx->inv_norm);
     if (idx->ones) { (void)hipFree(idx->ones); idx->ones = nullptr; idx->ones_valid = 0; }
+    drop_x8(idx);   // the int8 image is rebuilt for the new capacity by the next search that wants it
     idx->x = nx; idx->rownorm64 = nn; idx->inv_norm = ni; idx->cap = cap;
     return RQ_OK;
 }
@@ -116,7 +124,7 @@ extern "C" rq_index* rq_index_create(int dim, int n_devices, const int* device_i
 }
 
 static void free_ws(Workspace& w) {
-    void* p[] = {w.qh, w.q32, w.qn, w.bins, w.binkeys, w.cand, w.wgmax, w.rowcount, w.thr, w.done, w.ovf, w.fix_q, w.fix_scores, w.fix_rows, w.fix_keys, w.fix_status};
+    void* p[] = {w.qh, w.q32, w.qn, w.q8, w.qscale8, w.qeps8, w.bins, w.binkeys, w.cand, w.wgmax, w.rowcount, w.thr, w.done, w.ovf, w.fix_q, w.fix_scores, w.fix_rows, w.fix_keys, w.fix_status};
     for (void* q : p) if (q) (void)hipFree(q);
     w = Workspace();
 }
@@ -128,6 +136,9 @@ static void free_ctx(StreamCtx& c) {
         if (c.ring_qh[p]) (void)hipFree(c.ring_qh[p]);
         if (c.ring_q32[p]) (void)hipFree(c.ring_q32[p]);
         if (c.ring_qn[p]) (void)hipFree(c.ring_qn[p]);
+        if (c.ring_q8[p]) (void)hipFree(c.ring_q8[p]);
+        if (c.ring_qscale8[p]) (void)hipFree(c.ring_qscale8[p]);
+        if (c.ring_qeps8[p]) (void)hipFree(c.ring_qeps8[p]);
     }
     if (c.tail) (void)hipStreamDestroy(c.tail);
     for (int p = 0; p < 2; ++p) {
@@ -150,7 +161,7 @@ extern "C" void rq_index_destroy(rq_index* idx) {
     for (auto& ev : idx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (idx->hs_pin) (void)hipHostFree(idx->hs_pin);
     if (idx->hs_pin_q) (void)hipHostFree(idx->hs_pin_q);
-    void* p[] = {idx->add_stage, idx->x, idx->rownorm64, idx->inv_norm, idx->ones, idx->d_maxnorm, idx->h_dq, idx->h_dscores, idx->h_drows, idx->h_dstatus, idx->hs_dev, idx->dbg_stamps};
+    void* p[] = {idx->add_stage, idx->x, idx->rownorm64, idx->inv_norm, idx->ones, idx->x8, idx->scale8_cos, idx->scale8_ip, idx->d_stat8, idx->d_maxnorm, idx->h_dq, idx->h_dscores, idx->h_drows, idx->h_dstatus, idx->hs_dev, idx->dbg_stamps};
     for (void* q : p) if (q) (void)hipFree(q);
     if (idx->own_stream) (void)hipStreamDestroy(idx->own_stream);
     delete idx;
@@ -285,6 +296,8 @@ extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     else if (s == "tail_stop") idx->tail_stop = (int)v;
     else if (s == "epi" || s == "fused_epi") idx->epi = (int)v != 0;   // selection form of the 64-query scan (default variant and fused launch): 1 = positions inside the scores, 0 = compare / select
     else if (s == "profile_legacy") idx->profile_legacy = (int)v != 0;   // time scans with hipEventRecord around the launch (round 1) instead of dispatch-attached events
+    else if (s == "scan8") idx->scan8 = (int)v != 0;         // calls of <= 64 queries scan the int8 image of the shard (half the bytes)
+    else if (s == "thr_mult8") { if (!(v >= 1.05 && v <= 2.25)) return set_err(RQ_EINVAL, "thr_mult8 %g outside 1.05..2.25", v); idx->thr_mult8 = v; }
     else if (s == "use_hint") idx->use_hint = (int)v != 0;   // 0: rq_search_hint_next_device is ignored (A/B of the folded query preparation)
     else if (s == "poison_cand") idx->poison_cand = (int)v;   // test hook: candidate lists are filled with 0xff..ff keys before every tail
     else return set_err(RQ_EINVAL, "unknown option '%s'", name);
@@ -314,6 +327,10 @@ extern "C" double rq_get_option(const rq_index* idx, const char* name) {
     if (s == "profile_stride") return idx->profile_stride;
     if (s == "cu_count") return idx->cu_count;
     if (s == "max_row_norm") return idx->max_row_norm;
+    if (s == "scan8") return idx->scan8;
+    if (s == "thr_mult8") return idx->thr_mult8;
+    if (s == "scan8_row_err") return idx->x8_valid == idx->n && idx->x8 ? idx->max_e8 : -1.0;   // worst row's relative int8 error (-1: image not built)
+    if (s == "scan8_used") return (double)idx->scan8_used;   // searches that scanned the int8 image
     if (s == "hints_used") return (double)idx->hints_used;   // searches that found their queries prepared by the launch before them
     if (s == "max_sub_rel") return idx->max_sub_rel;   // largest share of a row's norm that sits in fp16-subnormal elements
     if (s == "max_sub_abs") return idx->max_sub_abs;
@@ -341,6 +358,9 @@ static int ensure_ws(Workspace& w, int bpad, int64_t stride, int64_t m, size_t c
         if (int r = ensure(w.qh, (size_t)bcap * RQ_DPAD)) return r;
         if (int r = ensure(w.q32, (size_t)bcap * RQ_DPAD)) return r;
         if (int r = ensure(w.qn, (size_t)bcap)) return r;
+        if (int r = ensure(w.q8, (size_t)bcap * RQ_DPAD)) return r;
+        if (int r = ensure(w.qscale8, (size_t)bcap)) return r;
+        if (int r = ensure(w.qeps8, (size_t)bcap)) return r;
         if (int r = ensure(w.wgmax, (size_t)bcap * RQ_WGMAX_STRIDE)) return r;
         if (int r = ensure(w.rowcount, (size_t)bcap)) return r;
         if (int r = ensure(w.thr, (size_t)bcap)) return r;
@@ -375,6 +395,35 @@ static int ensure_ones(rq_index* idx, hipStream_t s) {
     idx->ones_valid = idx->n;
     return RQ_OK;
 }
+
+// int8 scan ("scan8"): bring the int8 image of the shard up to date (rows appended since the last search that used it) and
+// read back the worst row's relative quantisation error.  One blocking 8-byte copy per append, nothing when up to date.
+static int ensure_x8(rq_index* idx, hipStream_t s) {
+    if (idx->x8 && idx->x8_valid == idx->n) return RQ_OK;
+    if (!idx->x8) {
+        hipError_t e = hipMalloc((void**)&idx->x8, (size_t)idx->cap * RQ_DPAD);
+        if (e == hipSuccess) e = hipMalloc((void**)&idx->scale8_cos, (size_t)idx->cap * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&idx->scale8_ip, (size_t)idx->cap * sizeof(float));
+        if (e == hipSuccess && !idx->d_stat8) e = hipMalloc((void**)&idx->d_stat8, sizeof(unsigned long long));
+        if (e != hipSuccess) { drop_x8(idx); return set_err(RQ_ENOMEM, "hipMalloc of the int8 image of %lld rows failed: %s", (long long)idx->cap, hipGetErrorString(e)); }
+        HIPCHK(hipMemsetAsync(idx->x8, 0, (size_t)idx->cap * RQ_DPAD, s));
+        HIPCHK(hipMemsetAsync(idx->scale8_cos, 0xff, (size_t)idx->cap * sizeof(float), s));   // pad rows: NaN (see grow)
+        HIPCHK(hipMemsetAsync(idx->scale8_ip, 0xff, (size_t)idx->cap * sizeof(float), s));
+        HIPCHK(hipMemsetAsync(idx->d_stat8, 0, sizeof(unsigned long long), s));
+        idx->x8_valid = 0; idx->max_e8 = 0.0;
+    }
+    HIPCHK(rq_quant_rows_launch(idx->x, idx->rownorm64, idx->x8_valid, idx->n, idx->x8, idx->scale8_cos, idx->scale8_ip, idx->d_stat8, s));
+    unsigned long long bits = 0;
+    HIPCHK(hipMemcpyAsync(&bits, idx->d_stat8, sizeof bits, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    __builtin_memcpy(&idx->max_e8, &bits, sizeof bits);
+    idx->x8_valid = idx->n;
+    return RQ_OK;
+}
+// the shard's share of the int8 scan's bound (unit-query units; the query's own share is added per query by the tail):
+// worst row + the fp32 steps between the exact int32 sum and the bin record (two scale products, two 6-bit truncations)
+static inline float scan8_eps(const rq_index* idx) { return (float)(idx->max_e8 * 1.000001 + 2e-5); }
+#define RQ_SCAN8_MAX_ROW_ERR 0.03   // beyond that the candidate sets stop being small: such a shard keeps the fp16 scan
 
 static int fill_empty(int B, int k, float* d_scores, int64_t* d_rows, uint64_t* d_keys, int* d_status, hipStream_t s) {
     HIPCHK(hipMemsetAsync(d_scores, 0, (size_t)B * k * sizeof(float), s));
@@ -495,6 +544,9 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             if (!cx.ring_qh[p]) HIPCHK(hipMalloc((void**)&cx.ring_qh[p], (size_t)64 * RQ_DPAD * sizeof(_Float16)));
             if (!cx.ring_q32[p]) HIPCHK(hipMalloc((void**)&cx.ring_q32[p], (size_t)64 * RQ_DPAD * sizeof(float)));
             if (!cx.ring_qn[p]) HIPCHK(hipMalloc((void**)&cx.ring_qn[p], (size_t)64 * sizeof(double)));
+            if (!cx.ring_q8[p]) HIPCHK(hipMalloc((void**)&cx.ring_q8[p], (size_t)64 * RQ_DPAD));
+            if (!cx.ring_qscale8[p]) HIPCHK(hipMalloc((void**)&cx.ring_qscale8[p], (size_t)64 * sizeof(float)));
+            if (!cx.ring_qeps8[p]) HIPCHK(hipMalloc((void**)&cx.ring_qeps8[p], (size_t)64 * sizeof(float)));
         }
     } else if (piped) {
         if (cx.fused_pending) { if (int r = flush_tails(idx, s)) return r; }
@@ -529,17 +581,33 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     _Float16* const qh = fused ? cx.ring_qh[slot] : w.qh;
     float* const q32 = fused ? cx.ring_q32[slot] : w.q32;
     double* const qn = fused ? cx.ring_qn[slot] : w.qn;
+    signed char* const q8 = fused ? cx.ring_q8[slot] : w.q8;
+    float* const qscale8 = fused ? cx.ring_qscale8[slot] : w.qscale8;
+    float* const qeps8 = fused ? cx.ring_qeps8[slot] : w.qeps8;
+    // int8 scan: one pass of <= 64 queries over the int8 image of the shard, when its worst row quantises well enough
+    bool use8 = false;
+    if (idx->scan8 && fast && bpad == 64) {
+        if (int r = ensure_x8(idx, s)) return r;
+        use8 = idx->max_e8 <= RQ_SCAN8_MAX_ROW_ERR;
+    }
+    if (use8) idx->scan8_used++;
     // ... unless the previous launch of this stream has already prepared exactly these queries (rq_search_hint_next_device)
     const bool prepared = fused && cx.prepped_q == d_q && cx.prepped_B == B && cx.prepped_slot == slot;
     cx.prepped_q = nullptr;
     if (prepared) idx->hints_used++;
-    if (!prepared) HIPCHK(rq_prep_queries_launch(d_q, idx->dim, B, bpad, qh, q32, qn, s));
+    if (!prepared) {
+        RqPrepArgs me{};
+        me.q = d_q; me.dim = idx->dim; me.B = B; me.nslots = bpad;
+        me.qh = qh; me.q32pad = q32; me.qnorm64 = qn; me.q8 = q8; me.qscale8 = qscale8; me.qeps8 = qeps8;
+        HIPCHK(rq_prep_queries_launch(me, s));
+    }
     // the queries announced for the NEXT call are prepared by extra workgroups of this call's fused launch
     RqPrepArgs pa{};
     if (fused && cx.hint_q) {
         const int nslot = (slot + 1) % 3;
         pa.q = cx.hint_q; pa.dim = idx->dim; pa.B = cx.hint_B; pa.nslots = 64;
         pa.qh = cx.ring_qh[nslot]; pa.q32pad = cx.ring_q32[nslot]; pa.qnorm64 = cx.ring_qn[nslot];
+        pa.q8 = cx.ring_q8[nslot]; pa.qscale8 = cx.ring_qscale8[nslot]; pa.qeps8 = cx.ring_qeps8[nslot];
     }
     // one scan grid for every pass of the call (the tail reads nwg partition maxima per query): the widest pass decides
     const int wg_cu = qb0 > 64 ? 1 : idx->wg_per_cu;   // every pass of more than 64 queries runs one 512-thread workgroup per CU
@@ -547,10 +615,11 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     if (!exact) {
         // non-temporal loads only for shards that cannot stay in the 256 MiB Infinity Cache between two scans
         // (measured: 192 MB shard 36 us with default policy vs 39 us nt; 1.5 GB shard 250 us nt vs 285 us default)
-        const bool nt = idx->nt < 0 ? (idx->n * (int64_t)(RQ_DPAD * 2) > ((int64_t)208 << 20)) : idx->nt != 0;
+        const bool nt = idx->nt < 0 ? (idx->n * (int64_t)(use8 ? RQ_DPAD : RQ_DPAD * 2) > ((int64_t)208 << 20)) : idx->nt != 0;
         for (int blk = 0, q0 = 0; blk < npass; q0 += pass_q[blk], ++blk) {
             const int qb = pass_q[blk];
             RqScanArgs a;
+            a.i8 = 0; a.qscale = nullptr;
             a.x = idx->x;
             a.row_scale = scale;
             a.qh = qh + (size_t)q0 * RQ_DPAD;
@@ -561,6 +630,10 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             a.nq_valid = idx->scan_nostore == 1 ? 0 : std::min(qb, B - q0);
             a.wgmax = w.wgmax + (size_t)q0 * RQ_WGMAX_STRIDE;
             a.wgmax_stride = RQ_WGMAX_STRIDE;
+            if (use8) {
+                a.i8 = 1; a.x = idx->x8; a.row_scale = metric == RQ_METRIC_IP ? idx->scale8_ip : idx->scale8_cos;
+                a.qh = (const _Float16*)q8; a.qscale = qscale8;
+            }
             const bool prof = idx->profile == 1 && idx->ev_used < 16384 && (idx->scan_seq++ % (uint64_t)idx->profile_stride) == 0;
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (prof) {   // the event pair rides on the scan dispatch itself (kernel start / end time stamps, no barrier packets)
@@ -584,18 +657,19 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
                 HIPCHK(rq_scan_tail_launch(a, cx.fused_tail, cx.fused_B, pa, nt, grid, idx->epi, s, e0, e1));
             } else if (fused && pa.nslots) {   // first call of a loop: no tail to carry yet, but queries to prepare
                 RqTailArgs none{};
-                none.nbins = nbins; none.m = none.k = 1;
+                none.nbins = nbins; none.m = none.k = 1; none.thr_mult = 2.25f;
                 HIPCHK(rq_scan_tail_launch(a, none, 0, pa, nt, grid, idx->epi, s, e0, e1));
             } else if (fused) HIPCHK(rq_scan_launch(a, 3, 1, 2, 4, nt, grid, idx->epi, s, e0, e1));
             else if (qb == 256) HIPCHK(rq_scan_wide_launch(a, idx->wide256, 256, nt, grid, s, e0, e1));
             else if (qb == 128 && idx->wide_batch == 2) HIPCHK(rq_scan_launch(a, 3, 4, 1, 8, nt, grid, 0, s, e0, e1));   // round 1's 8-wave pass
             else if (qb == 128) HIPCHK(rq_scan_wide_launch(a, idx->wide128, 128, nt, grid, s, e0, e1));
+            else if (use8) HIPCHK(rq_scan_launch(a, 3, 1, 2, 4, nt, grid, 1, s, e0, e1));
             else HIPCHK(rq_scan_launch(a, idx->ring, idx->prefetch, idx->kstage, 4, nt, grid, idx->epi, s, e0, e1));
             if (fused && pa.nslots) {
                 cx.prepped_q = cx.hint_q; cx.prepped_B = cx.hint_B; cx.prepped_slot = (slot + 1) % 3;
                 cx.hint_q = nullptr;
             }
-            if (prof) { if (idx->profile_legacy) HIPCHK(hipEventRecord(idx->events[idx->ev_used].second, s)); idx->ev_used++; }
+            if (prof) { if (idx->profile_legacy) HIPCHK(hipEventRecord(idx->events[idx->ev_used].second, s)); idx->ev_used++; idx->ev_bytes += idx->n * (int64_t)(use8 ? RQ_DPAD : RQ_DPAD * 2); }
         }
         if (fast) {
             hipStream_t ts = s;
@@ -609,7 +683,9 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             ta.bins = w.bins; ta.bins_stride = w.bins_stride; ta.nbins = nbins;
             ta.wgmax = w.wgmax; ta.wgmax_stride = RQ_WGMAX_STRIDE; ta.nwg = grid;
             ta.m = (int)std::min<int64_t>(k, idx->n); ta.metric = metric; ta.k = k;
-            ta.eps = scan_eps(idx, metric);
+            ta.eps = use8 ? scan8_eps(idx) : scan_eps(idx, metric);
+            ta.qeps = use8 ? qeps8 : nullptr;
+            ta.thr_mult = use8 ? (float)idx->thr_mult8 : 2.25f;
             ta.max_row_norm = (float)(idx->max_row_norm * (1.0 + 1e-6)); ta.row_offset = idx->row_offset;
             ta.cand = w.cand; ta.rowcount = w.rowcount; ta.done = w.done; ta.ovf = w.ovf;
             ta.out_scores = d_scores; ta.out_rows = d_rows; ta.out_keys = d_keys; ta.out_status = d_status;
@@ -635,7 +711,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             }
             if (int r = poison_cand(idx, ta, B, ts)) return r;
             HIPCHK(rq_tail_launch(ta, B, ts));
-            if (tprof) { HIPCHK(hipEventRecord(idx->events[idx->ev_used].second, ts)); idx->ev_used++; }
+            if (tprof) { HIPCHK(hipEventRecord(idx->events[idx->ev_used].second, ts)); idx->ev_used++; idx->ev_bytes += idx->n * (int64_t)(use8 ? RQ_DPAD : RQ_DPAD * 2); }
             if (piped) { HIPCHK(hipEventRecord(cx.ev_tail[par], cx.tail)); cx.tail_pending[par] = true; }
             return RQ_OK;
         }
@@ -946,7 +1022,7 @@ extern "C" int rq_get_timing(rq_index* idx, rq_timing* out) {
     }
     idx->t.scan_ms = ms;
     idx->t.scan_launches = (int64_t)idx->ev_used;
-    idx->t.scan_bytes = (int64_t)idx->ev_used * idx->n * (int64_t)(RQ_DPAD * 2);
+    idx->t.scan_bytes = idx->ev_bytes;
     *out = idx->t;
     return RQ_OK;
 }
@@ -960,7 +1036,7 @@ extern "C" int rq_reset_timing(rq_index* idx) {
     }
     RQ_ON_DEVICE(idx);
     HIPCHK(hipDeviceSynchronize());
-    idx->ev_used = 0;
+    idx->ev_used = 0; idx->ev_bytes = 0;
     idx->t = rq_timing{};
     return RQ_OK;
 }

@@ -22,6 +22,7 @@
 typedef _Float16 rq_half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 rq_half4 __attribute__((ext_vector_type(4)));
 typedef float rq_float4 __attribute__((ext_vector_type(4)));
+typedef int rq_int4 __attribute__((ext_vector_type(4)));
 
 // Order-preserving map float -> uint32 (larger float = larger uint). NaN must be removed first.
 __host__ __device__ static inline uint32_t rq_mono32(float f) {
@@ -87,6 +88,12 @@ __device__ __forceinline__ float rq_pos_score(float acc_times_scale, uint32_t po
     const float sc = __builtin_amdgcn_fmed3f(acc_times_scale, -3.4028234664e38f, 3.4028234664e38f);
     return __uint_as_float((__float_as_uint(sc) & 0xffffffc0u) | pos);
 }
+// value part times a positive scale, position bits kept (one more truncation of the 6 low bits: part of the error bound)
+__device__ __forceinline__ float rq_scale_pos(float x, float scale) {
+    const uint32_t b = __float_as_uint(x);
+    const float v = __uint_as_float(b & 0xffffffc0u) * scale;
+    return __uint_as_float((__float_as_uint(v) & 0xffffffc0u) | (b & 63u));
+}
 __device__ __forceinline__ void rq_insert3(float& m1, float& m2, float& m3, float x) {
     float n3, n2, n1;
     asm("v_med3_f32 %0, %1, %2, %3" : "=v"(n3) : "v"(m2), "v"(m3), "v"(x));
@@ -111,8 +118,9 @@ __device__ __forceinline__ double rq_wave_sum(double v) {
     return v;   // identical in every lane (xor butterfly)
 }
 // Query preparation of one query slot by one 256-thread workgroup (thread t owns elements t, 256 + t, 512 + t):
-// fp64 norm, qh = fp16(q / |q| * 2^12) (the factor: rq_select.hip), zero padded raw copy, slots >= B all zero.
-// `part` = 4 doubles of LDS.
+// fp64 norm, qh = fp16(q / |q| * 2^12) (the factor: rq_select.hip), zero padded raw copy, slots >= B all zero; and, when
+// wanted, the int8 image of the query with its scale and its measured quantisation error (rq_kernels.h RqPrepArgs).
+// `part` = 12 doubles of LDS.
 template <class PrepArgs>
 __device__ __forceinline__ void rq_prep_body(const PrepArgs& a, const int qi, double* part) {
     const int tid = threadIdx.x;
@@ -125,7 +133,10 @@ __device__ __forceinline__ void rq_prep_body(const PrepArgs& a, const int qi, do
         acc += (double)v[p] * (double)v[p];
     }
     acc = rq_wave_sum(acc);
-    if ((tid & 63) == 0) part[tid >> 6] = acc;
+    float am = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fabsf(v[2]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off, 64));
+    if ((tid & 63) == 0) { part[tid >> 6] = acc; part[4 + (tid >> 6)] = (double)am; }
     __syncthreads();
     const double nrm = sqrt((part[0] + part[1]) + (part[2] + part[3]));
     if (tid == 0 && qi < a.B) a.qnorm64[qi] = nrm;
@@ -135,6 +146,29 @@ __device__ __forceinline__ void rq_prep_body(const PrepArgs& a, const int qi, do
         const float f = nrm > 0.0 ? (float)((double)v[p] / nrm) * RQ_QSCALE : 0.f;
         a.qh[(size_t)qi * RQ_DPAD + i] = (_Float16)f;
         a.q32pad[(size_t)qi * RQ_DPAD + i] = v[p];
+    }
+    if (a.q8) {
+        const bool finite = nrm == nrm && nrm <= 1.7e308;   // (a NaN element makes the norm NaN, an infinite one infinite)
+        const float amax = (float)fmax(fmax(part[4], part[5]), fmax(part[6], part[7]));
+        const bool live = finite && amax > 0.f;
+        const float sq = live ? amax / 127.f : 0.f, inv = live ? 127.f / amax : 0.f;
+        double err = 0.0;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const float r = fminf(fmaxf(rintf(v[p] * inv), -127.f), 127.f);
+            const double d = live ? (double)v[p] - (double)sq * (double)r : 0.0;
+            err += d * d;
+            a.q8[(size_t)qi * RQ_DPAD + p * 256 + tid] = (signed char)(int)r;
+        }
+        err = rq_wave_sum(err);
+        if ((tid & 63) == 0) part[8 + (tid >> 6)] = err;
+        __syncthreads();
+        if (tid == 0) {
+            const double e = sqrt((part[8] + part[9]) + (part[10] + part[11]));
+            a.qscale8[qi] = live ? (float)((double)sq / nrm) : 1.f;
+            // rounded up to fp32; +inf for a non-finite query (never certified from the approximate pass)
+            a.qeps8[qi] = !finite ? __builtin_huge_valf() : (live ? (float)(e / nrm) * 1.000001f + 1e-30f : 0.f);
+        }
     }
 }
 

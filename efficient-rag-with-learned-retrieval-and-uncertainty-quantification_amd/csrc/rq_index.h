@@ -41,6 +41,9 @@ struct Workspace {
     _Float16* qh = nullptr;
     float* q32 = nullptr;
     double* qn = nullptr;
+    signed char* q8 = nullptr;    // int8 scan: the queries' int8 image, their scales and quantisation errors (rq_kernels.h RqPrepArgs)
+    float* qscale8 = nullptr;
+    float* qeps8 = nullptr;
     uint2* bins = nullptr;        // [bcap][bins_stride] scan output: one record per (query, quad), see rq_device.h
     uint64_t* binkeys = nullptr;
     uint64_t* cand = nullptr;
@@ -78,6 +81,9 @@ struct StreamCtx {
     _Float16* ring_qh[3] = {nullptr, nullptr, nullptr};
     float* ring_q32[3] = {nullptr, nullptr, nullptr};
     double* ring_qn[3] = {nullptr, nullptr, nullptr};
+    signed char* ring_q8[3] = {nullptr, nullptr, nullptr};
+    float* ring_qscale8[3] = {nullptr, nullptr, nullptr};
+    float* ring_qeps8[3] = {nullptr, nullptr, nullptr};
     const float* hint_q = nullptr;      // queries announced for the next fused call, not yet prepared
     int hint_B = 0;
     const float* prepped_q = nullptr;   // queries a launch has already prepared ...
@@ -95,13 +101,22 @@ struct rq_index {
     float* inv_norm = nullptr;
     float* ones = nullptr;
     int64_t ones_valid = 0;
+    // int8 image of the shard for the int8 scan (option "scan8"), built lazily for rows [0, x8_valid)
+    signed char* x8 = nullptr;
+    float* scale8_cos = nullptr;   // [cap] s_row / ||row||, pad rows NaN
+    float* scale8_ip = nullptr;    // [cap] s_row
+    unsigned long long* d_stat8 = nullptr;   // device: bits of the largest relative quantisation error of a row
+    int64_t x8_valid = 0;
+    double max_e8 = 0.0;           // host copy of that maximum over rows [0, x8_valid)
     double* d_maxnorm = nullptr;   // device: bits of the running maxima {row norm, relative, absolute fp16-subnormal mass of a row}
     double max_row_norm = 0.0, max_sub_rel = 0.0, max_sub_abs = 0.0;
     unsigned long long* dbg_stamps = nullptr;   // development (rq_debug_stamps)
+    int64_t scan8_used = 0;        // searches that scanned the int8 image
     int64_t hints_used = 0;        // rq_search_hint_next_device: searches that skipped their preparation launch
     uint64_t scan_seq = 0;         // scan launches seen while profile = 1 (every profile_stride-th one is timed)
     // options
-    int ring = 3, prefetch = 1, kstage = 2, wide_batch = 1, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, profile_stride = 1, scan_nostore = 0, fast_tail = 1, pipeline = 0, tail_stop = 0, poison_cand = 0, wide128 = 0, wide256 = 11, epi = 1, use_hint = 1, profile_legacy = 0;
+    int ring = 3, prefetch = 1, kstage = 2, wide_batch = 1, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, profile_stride = 1, scan_nostore = 0, fast_tail = 1, pipeline = 0, tail_stop = 0, poison_cand = 0, wide128 = 0, wide256 = 11, epi = 1, use_hint = 1, profile_legacy = 0, scan8 = 0;
+    double thr_mult8 = 1.25;       // int8 scan: threshold = P - thr_mult8 * bound (rq_tail_body.h)
     double eps = -1.0;
     std::map<hipStream_t, StreamCtx> ctx;
     hipStream_t own_stream = nullptr;
@@ -121,6 +136,7 @@ struct rq_index {
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t ev_used = 0;
+    int64_t ev_bytes = 0;          // algorithmic corpus bytes of the launches those events time (fp16 rows or their int8 image)
     rq_timing t = {};
 };
 

@@ -14,6 +14,10 @@ struct RqScanArgs {
     int nq_valid;             // queries of this block that are real (<= QB)
     float* wgmax;             // [QB][wgmax_stride] largest approximate score per (query, scan workgroup)
     int wgmax_stride;         // >= grid
+    // int8 scan (i8 = 1): x = the int8 image of the shard [rows_padded][768], row_scale = s_row / ||row|| (pad entries NaN),
+    // qh = int8 queries [QB][768], qscale[QB] = s_query / ||query||; approximate score = int32 sum * row_scale * qscale
+    int i8;
+    const float* qscale;
 };
 #define RQ_WGMAX_STRIDE 1024   // scan grids never exceed this many workgroups
 
@@ -43,9 +47,18 @@ struct RqPrepArgs {
     const float* q; int dim; int B;      // raw fp32 queries [B][dim]
     _Float16* qh; float* q32pad; double* qnorm64;
     int nslots;                          // workgroups = query slots written (padded batch size), 0 = none
+    // int8 image for the int8 scan (all three NULL = not wanted): q8[slot][768] = round(q / s), s = max|q_i| / 127;
+    // qscale8[slot] = s / ||q|| (1 for a zero / unused / non-finite query); qeps8[slot] = ||q - s q8|| / ||q||, the
+    // query's share of the certificate's error bound (+inf for a non-finite query)
+    signed char* q8; float* qscale8; float* qeps8;
 };
-hipError_t rq_prep_queries_launch(const float* q, int dim, int B, int Bpad, _Float16* qh, float* q32pad, double* qnorm64,
-                                  hipStream_t stream);
+hipError_t rq_prep_queries_launch(const RqPrepArgs& a, hipStream_t stream);   // a.nslots workgroups
+
+// int8 image of rows [row_begin, row_end) for the int8 scan: x8[row][768] = round(x / s_row), s_row = max|x_i| / 127;
+// scale_cos[row] = s_row / ||row|| (0 for a zero row), scale_ip[row] = s_row; stat[0] (device, double bits, running
+// maximum) = largest ||x - s x8|| / ||x|| of a row (+inf for a row with non-finite elements)
+hipError_t rq_quant_rows_launch(const void* x, const double* norm64, int64_t row_begin, int64_t row_end, signed char* x8,
+                                float* scale_cos, float* scale_ip, unsigned long long* stat, hipStream_t stream);
 
 // Pass 2: per query, the m best bins of bins[q][0..nbins) as sorted keys (score desc, bin asc); 0-padded.
 hipError_t rq_select_bins_launch(const uint2* bins, int64_t bins_stride, int64_t nbins, int B, int m,
@@ -105,6 +118,8 @@ struct RqTailArgs {
     uint64_t* cand;                                // [B][RQ_CAND_CAP] compact candidate keys
     int* rowcount; int* done; int* ovf;            // [B] each, zero before the launch, reset by the kernel
     float* out_scores; int64_t* out_rows; uint64_t* out_keys; int* out_status;
+    const float* qeps;                             // per query error share e_q (int8 scan): bound = e_q (1 + eps) + eps; null = eps alone
+    float thr_mult;                                // threshold T = P - thr_mult * bound (2.25 always certifies; less = fewer candidates, may not)
     unsigned long long* dbg;                       // development: per-workgroup (start, end) wall-clock stamps of the fused launch, or null
     int stop_after;                                // development: 0 = full kernel, 1..4 = return after phase A..D
 };

@@ -151,14 +151,76 @@ hipError_t rq_pad_f16_launch(const void* src, int dim, int64_t n, void* dst, hip
 // 2^-26 of the unit query -- at most sqrt(768) * 2^-26 = 4e-7 of score error, against 1.7e-3 without the scaling.
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rq_prep_queries_kernel(RqPrepArgs a) {
-    __shared__ double part[4];
+    __shared__ double part[12];
     rq_prep_body(a, (int)blockIdx.x, part);
 }
-hipError_t rq_prep_queries_launch(const float* q, int dim, int B, int Bpad, _Float16* qh, float* q32pad, double* qnorm64,
-                                  hipStream_t stream) {
-    RqPrepArgs a;
-    a.q = q; a.dim = dim; a.B = B; a.qh = qh; a.q32pad = q32pad; a.qnorm64 = qnorm64; a.nslots = Bpad;
-    hipLaunchKernelGGL(rq_prep_queries_kernel, dim3(Bpad), dim3(256), 0, stream, a);
+hipError_t rq_prep_queries_launch(const RqPrepArgs& a, hipStream_t stream) {
+    if (a.nslots <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rq_prep_queries_kernel, dim3(a.nslots), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------------------
+// int8 image of stored rows (one wave per row), see rq_kernels.h rq_quant_rows_launch.  Symmetric per-row scale from the
+// row's largest magnitude: no clipping, every element within s/2 of its image.  The measured relative error of the
+// worst row is what the int8 scan's certificate rests on, so it is summed in fp64 from the values the scan will use.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rq_quant_rows_kernel(const char* x, const double* norm64, int64_t row_begin, int64_t row_end,
+                                                            signed char* x8, float* scale_cos, float* scale_ip, unsigned long long* stat) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    double mx = 0.0;
+    for (int64_t row = row_begin + wave; row < row_end; row += nwaves) {
+        const char* r = x + row * (RQ_DPAD * 2);
+        float f[12];
+        float am = 0.f;
+        bool bad = false;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const rq_half4 v = *(const rq_half4*)(r + p * 512 + lane * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f[p * 4 + e] = (float)v[e];
+                bad |= !(fabsf(f[p * 4 + e]) <= 65504.f);
+                am = fmaxf(am, fabsf(f[p * 4 + e]));
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off, 64));
+        bad = __ballot(bad) != 0ull;
+        const double nrm = norm64[row];
+        const bool live = !bad && am > 0.f && nrm > 0.0;
+        const float sr = live ? am / 127.f : 0.f, inv = live ? 127.f / am : 0.f;
+        double err = 0.0;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            uint32_t packed = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float q = fminf(fmaxf(rintf(f[p * 4 + e] * inv), -127.f), 127.f);
+                const double d = live ? (double)f[p * 4 + e] - (double)sr * (double)q : 0.0;
+                err += d * d;
+                packed |= ((uint32_t)(int)q & 0xffu) << (8 * e);
+            }
+            *(uint32_t*)(x8 + row * RQ_DPAD + p * 256 + lane * 4) = packed;
+        }
+        err = rq_wave_sum(err);
+        if (lane == 0) {
+            scale_cos[row] = live ? (float)((double)sr / nrm) : 0.f;
+            scale_ip[row] = sr;
+        }
+        if (bad) mx = (double)__builtin_huge_valf();
+        else if (live) mx = fmax(mx, sqrt(err) / nrm);
+    }
+    if (lane == 0 && mx > 0.0) atomicMax(&stat[0], (unsigned long long)__double_as_longlong(mx));
+}
+hipError_t rq_quant_rows_launch(const void* x, const double* norm64, int64_t row_begin, int64_t row_end, signed char* x8,
+                                float* scale_cos, float* scale_ip, unsigned long long* stat, hipStream_t stream) {
+    if (row_end <= row_begin) return hipSuccess;
+    const int64_t rows = row_end - row_begin;
+    const int grid = (int)((rows + 3) / 4 < 8192 ? (rows + 3) / 4 : 8192);
+    hipLaunchKernelGGL(rq_quant_rows_kernel, dim3(grid), dim3(256), 0, stream, (const char*)x, norm64, row_begin, row_end, x8, scale_cos, scale_ip, stat);
     return hipGetLastError();
 }
 

@@ -5,10 +5,10 @@
 #include "rq_kernels.h"
 #include "rq_final_body.h"
 
-#define RQ_TAIL_HITCAP 256     // candidate bins one workgroup can hold
+#define RQ_TAIL_HITCAP 768     // candidate bins one workgroup can hold
 #define RQ_TAIL_JOBCAP 2048    // row jobs one workgroup can hold
 
-// LDS of one tail workgroup (28.8 KB: query 3 KB, hit / job lists 9 KB, 2048-key ranking buffer 16 KB): static in
+// LDS of one tail workgroup (30.8 KB: query 3 KB, hit / job lists 11 KB, 2048-key ranking buffer 16 KB): static in
 // rq_tail_kernel, carved from the scan's LDS in the fused kernel.
 struct __attribute__((aligned(16))) RqTailLds {
     float qs[RQ_DPAD];            // the raw query, shared by the four waves
@@ -31,6 +31,9 @@ __device__ __forceinline__ void rq_tail_body(const RqTailArgs& a, const int chun
     int* const hits = L.hits;
     int* const jobs = L.jobs;
     float& thr_s = L.thr_s;
+    // this query's error bound in unit-query units: the shard's (a.eps) alone, or -- int8 scan -- together with the query's own
+    // measured quantisation error e_q: |approx - exact| <= e_q + (1 + e_q) e_rows  <=  e_q (1 + eps) + eps
+    const float eps_q = a.qeps ? a.qeps[q] * (1.f + a.eps) + a.eps : a.eps;
     int &nhit_s = L.nhit_s, &njob_s = L.njob_s, &base_s = L.base_s, &last_s = L.last_s, &total_s = L.total_s, &ovf_s = L.ovf_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float NEG_INF = -__builtin_huge_valf();
@@ -57,7 +60,7 @@ __device__ __forceinline__ void rq_tail_body(const RqTailArgs& a, const int chun
     // ---- A. threshold.  P = the m-th largest partition maximum (m = the k rows wanted; partitions = groups of the
     //      scan's per-workgroup maxima, distinct workgroups own distinct bins), found by a ballot radix select in
     //      wave 0 and truncated to the top 20 key bits (a slightly lower value).  At least m rows have an approximate
-    //      score >= P, so the k-th exact score is >= P - eps.  T = P - 2 eps - margin therefore always satisfies the
+    //      score >= P, so the k-th exact score is >= P - eps.  T = P - 2 eps - margin (thr_mult 2.25) therefore always satisfies the
     //      certificate T + eps < s_k: the candidate set adapts to how dense the scores are around the k-th one
     //      (about k + 2 rows on Gaussian data, hundreds inside a tight cluster) instead of failing there.
     //      64 partitions (one per lane) for m <= 8, 256 for m <= 64, else 512: more partitions = tighter P.
@@ -89,8 +92,8 @@ __device__ __forceinline__ void rq_tail_body(const RqTailArgs& a, const int chun
             float T0 = NEG_INF;
             if (prefix > rq_mono32(NEG_INF)) {
                 const float P = rq_unmono32(prefix);
-                const float e = a.metric == 0 ? a.eps : a.eps * a.max_row_norm;
-                T0 = P - 2.25f * e - 4e-6f * fabsf(P);   // margin: the 1e-6 relative slack of the certificate and fp32 rounding
+                const float e = a.metric == 0 ? eps_q : eps_q * a.max_row_norm;
+                T0 = P - a.thr_mult * e - 4e-6f * fabsf(P);   // margin: the 1e-6 relative slack of the certificate and fp32 rounding
             }
             thr_s = T0;
         }
@@ -234,7 +237,7 @@ __device__ __forceinline__ void rq_tail_body(const RqTailArgs& a, const int chun
     if (qn < 0.0) qn = query_norm();   // uniform: this workgroup had no hits of its own
 
     RqFinalCore c;
-    c.cand = a.cand + (int64_t)q * RQ_CAND_CAP; c.metric = a.metric; c.eps = a.eps;
+    c.cand = a.cand + (int64_t)q * RQ_CAND_CAP; c.metric = a.metric; c.eps = eps_q;
     c.max_row_norm = a.max_row_norm; c.k = a.k; c.row_offset = a.row_offset; c.n_rows = a.n_rows;
     c.out_scores = a.out_scores + (int64_t)q * a.k; c.out_rows = a.out_rows + (int64_t)q * a.k;
     c.out_keys = a.out_keys ? a.out_keys + (int64_t)q * a.k : nullptr; c.out_status = a.out_status + q;

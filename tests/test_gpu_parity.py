@@ -1219,3 +1219,31 @@ def test_baseline_config0_10k_passages_100_queries_top10(tmp_path):
         single = idx.search_vectors(q[b], top_k=10)[0]
         assert single == batched[b]
     assert orc.recall_at_k(np.array([[int(d[1:]) for d, _, _ in r] for r in batched]), gr) == 1.0
+
+
+# ---- int8 scan (option "scan8"): half the corpus bytes per pass, same exact answers -----------------------------------
+def test_int8_scan_matches_oracle_100k(corpus100k):
+    """Option scan8: calls of <= 64 queries scan the int8 image of the shard (csrc/rq_scan.hip I8, per-row and per-query
+    scales, exact int32 sums) and re-score the candidates from the fp16 rows in fp64 as before.  The certificate's bound is
+    the MEASURED quantisation error of the worst row plus the query's own.  Rows identical to the oracle, scores within
+    1e-6, for cosine and inner product, k = 1 .. 100, ragged batches, a zero query, a query equal to a stored row."""
+    idx, x16 = corpus100k
+    idx.set_option("scan8", 1)
+    try:
+        before = int(idx.get_option("scan8_used"))
+        for B, k in ((64, 10), (1, 1), (17, 10), (64, 100), (5, 50)):
+            q = orc.synthetic_queries(B, 768, seed=8000 + B + k)
+            if B >= 5:
+                q[1] = 0
+                q[2] = x16[777].astype(np.float32)
+            _check(idx, x16, q, k)
+        _check(idx, x16, 3.0 * orc.synthetic_queries(9, 768, seed=78), 10, nat.METRIC_IP)
+        assert int(idx.get_option("scan8_used")) == before + 6
+        e8 = idx.get_option("scan8_row_err")
+        assert 0.005 < e8 < 0.02, e8                      # Gaussian unit rows: ~0.008 typical, ~0.013 worst
+        t = idx.timing()
+        assert t["exact_scans"] == 0
+        _check(idx, x16, orc.synthetic_queries(130, 768, seed=8), 10)      # more than 64 queries: the fp16 passes, unchanged
+        assert int(idx.get_option("scan8_used")) == before + 6
+    finally:
+        idx.set_option("scan8", 0)
