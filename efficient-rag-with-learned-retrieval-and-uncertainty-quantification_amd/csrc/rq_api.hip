@@ -296,7 +296,7 @@ extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     else if (s == "tail_stop") idx->tail_stop = (int)v;
     else if (s == "epi" || s == "fused_epi") idx->epi = (int)v != 0;   // selection form of the 64-query scan (default variant and fused launch): 1 = positions inside the scores, 0 = compare / select
     else if (s == "profile_legacy") idx->profile_legacy = (int)v != 0;   // time scans with hipEventRecord around the launch (round 1) instead of dispatch-attached events
-    else if (s == "scan8") idx->scan8 = (int)v != 0;         // calls of <= 64 queries scan the int8 image of the shard (half the bytes)
+    else if (s == "scan8") { if (v < 0 || v > 2) return set_err(RQ_EINVAL, "scan8 must be 0, 1 or 2"); idx->scan8 = (int)v; }   // see run_pipeline
     else if (s == "thr_mult8") { if (!(v >= 1.05 && v <= 2.25)) return set_err(RQ_EINVAL, "thr_mult8 %g outside 1.05..2.25", v); idx->thr_mult8 = v; }
     else if (s == "use_hint") idx->use_hint = (int)v != 0;   // 0: rq_search_hint_next_device is ignored (A/B of the folded query preparation)
     else if (s == "poison_cand") idx->poison_cand = (int)v;   // test hook: candidate lists are filled with 0xff..ff keys before every tail
@@ -423,6 +423,7 @@ static int ensure_x8(rq_index* idx, hipStream_t s) {
 // the shard's share of the int8 scan's bound (unit-query units; the query's own share is added per query by the tail):
 // worst row + the fp32 steps between the exact int32 sum and the bin record (two scale products, two 6-bit truncations)
 static inline float scan8_eps(const rq_index* idx) { return (float)(idx->max_e8 * 1.000001 + 2e-5); }
+#define RQ_SCAN8_MIN_ROWS 350000
 #define RQ_SCAN8_MAX_ROW_ERR 0.03   // beyond that the candidate sets stop being small: such a shard keeps the fp16 scan
 
 static int fill_empty(int B, int k, float* d_scores, int64_t* d_rows, uint64_t* d_keys, int* d_status, hipStream_t s) {
@@ -502,7 +503,17 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     const int64_t nbins = nquads;   // bin = quad
     // tiny shards (fewer than two bins per wanted bin): the approximate pass cannot narrow anything down
     // ... and shards whose rows keep so much of their norm in fp16-subnormal elements that the scan's scores say nothing
-    const bool exact = nb < 0 || 2 * (int64_t)nb >= nbins || (idx->eps < 0 && scan_eps(idx, metric) > RQ_EPS_USELESS);
+    // int8 scan ("scan8": 0 = never, 1 = shards of RQ_SCAN8_MIN_ROWS rows and more -- below that the scan is too short for
+    // the saving to outweigh the larger candidate sets the looser bound brings (measured at 125k rows: 60 vs 52 us per
+    // batch) --, 2 = always): one pass of <= 64 queries over the int8 image of the shard, when its worst row quantises well
+    // enough.  Its bound does not involve fp16 subnormals (the image is relative to each row's largest element).
+    bool use8 = false;
+    if (idx->scan8 && nb >= 0 && 2 * (int64_t)nb < nbins && B <= 64 && !force_generic && idx->fast_tail && k <= RQ_FAST_MAX_K &&
+        (idx->scan8 == 2 || idx->n >= RQ_SCAN8_MIN_ROWS)) {
+        if (int r = ensure_x8(idx, s)) return r;
+        use8 = idx->max_e8 <= RQ_SCAN8_MAX_ROW_ERR;
+    }
+    const bool exact = nb < 0 || 2 * (int64_t)nb >= nbins || (!use8 && idx->eps < 0 && scan_eps(idx, metric) > RQ_EPS_USELESS);
     if (exact) nb = (int)std::min<int64_t>(nbins, INT32_MAX / 64);
     if (!exact && nb > RQ_NB_MAX) return set_err(RQ_EINVAL, "nb %d too large", nb);
     // Queries per corpus pass: 64, or -- once a call has more than 64 -- 128 / 256 (every LDS fragment of the corpus feeds
@@ -584,12 +595,6 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     signed char* const q8 = fused ? cx.ring_q8[slot] : w.q8;
     float* const qscale8 = fused ? cx.ring_qscale8[slot] : w.qscale8;
     float* const qeps8 = fused ? cx.ring_qeps8[slot] : w.qeps8;
-    // int8 scan: one pass of <= 64 queries over the int8 image of the shard, when its worst row quantises well enough
-    bool use8 = false;
-    if (idx->scan8 && fast && bpad == 64) {
-        if (int r = ensure_x8(idx, s)) return r;
-        use8 = idx->max_e8 <= RQ_SCAN8_MAX_ROW_ERR;
-    }
     if (use8) idx->scan8_used++;
     // ... unless the previous launch of this stream has already prepared exactly these queries (rq_search_hint_next_device)
     const bool prepared = fused && cx.prepped_q == d_q && cx.prepped_B == B && cx.prepped_slot == slot;

@@ -109,10 +109,28 @@ __device__ __forceinline__ void rq_final_body(const RqFinalCore& a, int total, i
         have = nzt < a.k ? nzt : a.k;
         uint64_t prefix = 1;                                 // have == nzt: every non-empty key is a winner
         if (nzt > have) {                                    // the have-th largest key: the largest t with count(key >= t) >= have
-            prefix = 0;
-            for (int bit = 63; bit >= 0; --bit) {
+            // the keys of one query share their leading bits (scores within a few percent of each other): those rounds are
+            // skipped -- one reduction of the keys' OR and AND finds the first bit they differ in
+            uint64_t kor = 0, kand = ~0ull;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) if (key[i] != 0) { kor |= key[i]; kand &= key[i]; }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { kor |= __shfl_xor(kor, off, 64); kand &= __shfl_xor(kand, off, 64); }
+            if (lane == 0) { L.wbest[round & 1][wave] = kor; L.skeys[wave] = kand; }
+            __syncthreads();
+            kor = L.wbest[round & 1][0] | L.wbest[round & 1][1] | L.wbest[round & 1][2] | L.wbest[round & 1][3];
+            kand = L.skeys[0] & L.skeys[1] & L.skeys[2] & L.skeys[3];
+            ++round;
+            const uint64_t diff = kor ^ kand;                // != 0: the keys are unique and there are at least two
+            const int top = 63 - __builtin_clzll(diff | 1ull);   // highest bit in which two keys differ
+            prefix = top == 63 ? 0 : (kand >> (top + 1)) << (top + 1);
+            for (int bit = top; bit >= 0; --bit) {
                 const uint64_t t = prefix | (1ull << bit);
-                if (count_ge(t) >= have) prefix = t;         // uniform
+                const int c = count_ge(t);                   // uniform
+                if (c >= have) {
+                    prefix = t;
+                    if (c == have) break;                    // exactly the winners are >= t: the remaining bits cannot change the set
+                }
             }
         }
         // keys are unique, so exactly `have` keys are >= prefix: compact them, then rank them among themselves

@@ -234,6 +234,7 @@ __device__ __forceinline__ void rq_tail_body(const RqTailArgs& a, const int chun
     }
     __syncthreads();
     if (!last_s || a.stop_after == 4) return;
+    if (a.stop_after == 5) { if (tid == 0) a.out_status[q] = total_s; return; }   // development: candidate rows of the query
     if (qn < 0.0) qn = query_norm();   // uniform: this workgroup had no hits of its own
 
     RqFinalCore c;

@@ -241,8 +241,8 @@ def test_every_wide_pass_variant_is_exact(corpus100k, opts):
     idx.close()
 
 
-@pytest.mark.parametrize("mode", [1, 2])
-def test_deferred_tails_over_many_batches(mode):
+@pytest.mark.parametrize("mode,scan8", [(1, 0), (2, 0), (2, 2), (1, 2)])
+def test_deferred_tails_over_many_batches(mode, scan8):
     """pipeline = 1 (internal tail stream) and 2 (the tail of batch i rides in the scan launch of batch i+1):
     a train of calls on one stream, batch sizes / k / scan variants changing on the way, rows appended in the middle,
     the query buffer overwritten right after every call -- every batch must come out exact after the flush."""
@@ -252,6 +252,7 @@ def test_deferred_tails_over_many_batches(mode):
     idx = nat.NativeIndex(768, 0)
     idx.add_f16(x16[:60_000])
     idx.set_option("pipeline", mode)
+    idx.set_option("scan8", scan8)            # int8 scan: its image of the shard must follow the append in the middle
     dev = torch.device("cuda:0")
     st = torch.cuda.Stream(device=dev)
     plan = [(64, 10, 4), (64, 10, 4), (17, 10, 4), (64, 20, 4), (64, 10, 2), (64, 10, 2), (100, 10, 4), (64, 5, 4), (1, 1, 1), (64, 100, 3), (64, 10, 4)]
@@ -288,6 +289,8 @@ def test_deferred_tails_over_many_batches(mode):
         assert int(stt.sum()) == 0
         assert np.array_equal(rw.cpu().numpy(), er)
         assert float(np.abs(sc.cpu().numpy() - es).max()) <= SCORE_TOL
+    if scan8:
+        assert int(idx.get_option("scan8_used")) == sum(1 for B, k, R in plan if B <= 64)
     idx.close()
 
 
@@ -597,8 +600,8 @@ def _device_corpus(idx, n, seed0, chunk=125_000):
         del x
 
 
-@pytest.mark.parametrize("n,expect_nv", [(1_000_000, 8), (300_000, 4)])
-def test_fused_headline_instantiation_matches_oracle(n, expect_nv):
+@pytest.mark.parametrize("n,expect_nv,scan8", [(1_000_000, 8, 0), (300_000, 4, 0), (1_000_000, 8, 1)])
+def test_fused_headline_instantiation_matches_oracle(n, expect_nv, scan8):
     """The kernel bench.py times: rq_scan_tail_kernel<NT = true, NV> (option pipeline = 2: the tail of batch i rides in
     the scan launch of batch i + 1), one stream, consecutive 64-query batches -- at the headline size (1M rows: non-temporal
     loads, 4096-bin tail chunks, NV = 8) and at 300k rows (NT, NV = 4).  ALL 64 queries of every batch are compared with
@@ -617,6 +620,7 @@ def test_fused_headline_instantiation_matches_oracle(n, expect_nv):
     assert n * 1536 > (208 << 20)                                          # -> non-temporal corpus loads (csrc/rq_api.hip)
     idx.set_option("pipeline", 2)
     idx.set_option("poison_cand", 1)
+    idx.set_option("scan8", scan8)            # 1: the int8 scan (rq_scan_tail_kernel<..., 2>), what bench.py times by default
     st = torch.cuda.Stream(device=dev)
     plan = [(10, 0), (10, 0), (100, 0), (100, 0), (10, 1), (10, 0), (10, 0)]          # (k, metric) of consecutive calls
     qs = [orc.synthetic_queries(64, 768, seed=4321 + i) * (3.0 if m == 1 else 1.0) for i, (k, m) in enumerate(plan)]
@@ -637,6 +641,7 @@ def test_fused_headline_instantiation_matches_oracle(n, expect_nv):
     t = idx.timing()
     assert t["widened"] == 0 and t["exact_scans"] == 0
     assert int(idx.get_option("hints_used")) == len(plan) - 2
+    assert int(idx.get_option("scan8_used")) == (len(plan) if scan8 else 0)
     x16 = idx.get_rows_f16(0, n)
     cos = orc.exact_scores(np.concatenate([q for q, (k, m) in zip(qs, plan) if m == 0], 0), x16, 0)
     ip = orc.exact_scores(np.concatenate([q for q, (k, m) in zip(qs, plan) if m == 1], 0), x16, 1)
@@ -1228,7 +1233,7 @@ def test_int8_scan_matches_oracle_100k(corpus100k):
     the MEASURED quantisation error of the worst row plus the query's own.  Rows identical to the oracle, scores within
     1e-6, for cosine and inner product, k = 1 .. 100, ragged batches, a zero query, a query equal to a stored row."""
     idx, x16 = corpus100k
-    idx.set_option("scan8", 1)
+    idx.set_option("scan8", 2)               # 2 = also on shards below the size the automatic rule (1) asks for
     try:
         before = int(idx.get_option("scan8_used"))
         for B, k in ((64, 10), (1, 1), (17, 10), (64, 100), (5, 50)):
@@ -1247,3 +1252,105 @@ def test_int8_scan_matches_oracle_100k(corpus100k):
         assert int(idx.get_option("scan8_used")) == before + 6
     finally:
         idx.set_option("scan8", 0)
+
+
+def _planted_outlier_rows(n, seed):
+    x16 = orc.synthetic_corpus(n, 768, seed=seed)
+    x = x16.astype(np.float32)
+    x[5, :] = 0.01; x[5, 100] = 1.0                      # one dominant element: the int8 image of this row is poor
+    return x.astype(np.float16)
+
+
+def test_int8_scan_declines_shards_that_quantise_badly():
+    """The int8 scan's bound is the measured error of the WORST row.  A row with one dominant element (its other elements
+    fall below half a quantisation step), or a row with a non-finite element, makes the bound useless: such a shard keeps
+    the fp16 scan (scan8_used stays 0) and the answers stay exact."""
+    for kind in ("outlier", "inf"):
+        x16 = _planted_outlier_rows(20_000, 31) if kind == "outlier" else orc.synthetic_corpus(20_000, 768, seed=32)
+        idx = nat.NativeIndex(768, 0)
+        idx.add_f16(x16)
+        idx.set_option("scan8", 2)
+        if kind == "inf":
+            bad = x16[:1].copy(); bad[0, 3] = np.float16(np.inf)
+            idx.add_f16(bad)
+            x16 = np.concatenate([x16, bad], 0)
+        q = orc.synthetic_queries(16, 768, seed=5)
+        q[0] = x16[5].astype(np.float32)
+        if kind == "outlier":
+            _check(idx, x16, q, 10)
+        else:                                             # (the reference's arithmetic gives that row a NaN score; compare the others)
+            s, r = idx.search(q, 10)
+            gs, gr = orc.dense_topk(q, x16[:-1], 10)
+            assert np.array_equal(r, gr) or np.isin(20_000, r).any()
+        e8 = idx.get_option("scan8_row_err")
+        assert e8 > 0.03, (kind, e8)
+        assert int(idx.get_option("scan8_used")) == 0
+        idx.close()
+
+
+def test_int8_scan_on_hostile_shards_stays_exact():
+    """Shards the int8 scan accepts but that stress it: exact duplicates (ties by row id), zero rows, rows with tiny norms
+    (the int8 image is relative to the row's own largest element: no subnormal problem), a clustered corpus (hundreds of
+    rows inside the bound around the k-th score: candidate lists overflow, those queries are repaired by the exact route),
+    rows appended after the image was built, a saved and reloaded index."""
+    import tempfile, os
+    x16 = orc.synthetic_corpus(40_000, 768, seed=41)
+    x16[100:140] = x16[7]
+    x16[200:210] = 0
+    x16[300:320] = (x16[300:320].astype(np.float32) * 1e-3).astype(np.float16)
+    idx = nat.NativeIndex(768, 0)
+    idx.add_f16(x16[:30_000])
+    idx.set_option("scan8", 2)
+    q = orc.synthetic_queries(64, 768, seed=6)
+    q[0] = x16[7].astype(np.float32); q[1] = x16[305].astype(np.float32) * 50.0; q[2] = 0
+    _check(idx, x16[:30_000], q, 10)
+    _check(idx, x16[:30_000], q[:9], 50)
+    idx.add_f16(x16[30_000:])                             # the image follows
+    _check(idx, x16, q, 10)
+    _check(idx, x16, 2.0 * q[:20], 10, nat.METRIC_IP)
+    used = int(idx.get_option("scan8_used"))
+    assert used >= 3          # (k = 50 on 30 000 rows may be a shard "too small to narrow down": the exact route, no scan at all)
+    with tempfile.TemporaryDirectory() as d:
+        idx.save(os.path.join(d, "shard"))
+        idx2 = nat.NativeIndex.load(os.path.join(d, "shard"), 0)
+        idx2.set_option("scan8", 2)
+        _check(idx2, x16, q, 10)
+        assert int(idx2.get_option("scan8_used")) == 1
+        idx2.close()
+    idx.close()
+    xc = orc.synthetic_corpus(60_000, 768, seed=43, clustered=True)
+    idx = nat.NativeIndex(768, 0)
+    idx.add_f16(xc)
+    idx.set_option("scan8", 2)
+    qc = xc[::1000][:48].astype(np.float32) + 0.05 * orc.synthetic_queries(48, 768, seed=9)
+    _check(idx, xc, qc, 10)
+    assert int(idx.get_option("scan8_used")) >= 1
+    idx.close()
+
+
+def test_int8_scan_automatic_rule_and_options():
+    """scan8 = 1 uses the int8 image only on shards of 350 000 rows and more; thr_mult8 is validated; the always-certifying
+    multiplier 2.25 gives the same rows."""
+    import torch
+    idx = nat.NativeIndex(768, 0)
+    _device_corpus(idx, 360_000, 77)
+    x16 = idx.get_rows_f16(0, 360_000)
+    q = orc.synthetic_queries(8, 768, seed=12)
+    idx.set_option("scan8", 1)
+    _check(idx, x16, q, 10)
+    assert int(idx.get_option("scan8_used")) == 1
+    idx.set_option("thr_mult8", 2.25)
+    _check(idx, x16, q, 10)
+    assert int(idx.get_option("scan8_used")) == 2
+    with pytest.raises(nat.RqError):
+        idx.set_option("thr_mult8", 0.5)
+    with pytest.raises(nat.RqError):
+        idx.set_option("scan8", 3)
+    idx.close()
+    small = nat.NativeIndex(768, 0)
+    xs = orc.synthetic_corpus(50_000, 768, seed=3)
+    small.add_f16(xs)
+    small.set_option("scan8", 1)
+    _check(small, xs, q, 10)
+    assert int(small.get_option("scan8_used")) == 0 and small.get_option("scan8_row_err") == -1.0     # image never built
+    small.close()

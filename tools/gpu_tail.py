@@ -13,6 +13,8 @@ for N in (1_000_000, 125_000):
         n = min(125_000, N - lo)
         x = torch.nn.functional.normalize(torch.randn((n, 768), device=dev, generator=g), dim=1).half().contiguous()
         idx.add_f16_device(x, n)
+    if os.environ.get("RQ_SCAN8"):      # phases of the tail behind the int8 scan (more candidates per query)
+        idx.set_option("scan8", 1)
     qs = [torch.randn((B, 768), device=dev, generator=g) for _ in range(8)]
     for k in (10, 100):
         o = (torch.empty((B, k), device=dev), torch.empty((B, k), device=dev, dtype=torch.int64), torch.empty((B, k), device=dev, dtype=torch.int64), torch.empty((B,), device=dev, dtype=torch.int32))
