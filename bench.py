@@ -46,6 +46,9 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=0, help="caller streams the batches alternate over (0 = 1 at one GPU, 2 at several)")
     ap.add_argument("--event-stride", type=int, default=4, help="HIP events around every n-th scan launch of the timed region")
+    ap.add_argument("--scan", choices=("auto", "fp16", "int8"), default="auto",
+                    help="corpus operand of the scan: fp16 rows, their int8 image (half the bytes; candidates are still re-scored from "
+                         "the fp16 rows in fp64), or the library's rule (int8 image on shards of 350k rows and more)")
     ap.add_argument("--no-hint", action="store_true", help="do not announce the next batch (rq_search_hint_next_device): every call prepares its own queries in a separate launch")
     ap.add_argument("--pipeline", type=int, default=2, help="deferred tails: 1 = on the library's internal stream, 2 = fused into the next scan launch")
     ap.add_argument("--workload", default="headline", choices=["headline", "config2", "config3", "config4"],
@@ -100,6 +103,7 @@ def main() -> None:
     idx.reserve(max(n_local, 1))
     idx.set_row_offset(row_lo)
     idx.set_option("pipeline", args.pipeline)
+    idx.set_option("scan8", {"auto": 1, "fp16": 0, "int8": 2}[args.scan])
     for opt in filter(None, os.environ.get("RQ_BENCH_OPTS", "").split(",")):      # development: e.g. RQ_BENCH_OPTS=wg_per_cu=3
         name, val = opt.split("=")
         idx.set_option(name, float(val))
@@ -245,6 +249,7 @@ def main() -> None:
     idx.set_option("profile", 1 if live_events else 0)
     idx.set_option("profile_stride", max(1, args.event_stride))
     idx.reset_timing()
+    scan8_before = int(idx.get_option("scan8_used"))
     sync_all()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -264,6 +269,7 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     timing = idx.timing()
+    int8_scan = int(idx.get_option("scan8_used")) - scan8_before == args.steps      # every timed search scanned the int8 image
     # Results of the TIMED path, copied out before anything else runs: the calibration below re-uses the same slots with
     # the plain (pipeline 0) path, and the exactness checks further down must describe the kernel that was timed.
     nslots_used = min(N_QUERY_BATCHES, args.steps)
@@ -290,12 +296,14 @@ def main() -> None:
     if not live_events:
         timing = iso      # no per-launch events in the timed region: report the calibration launches
     scan_us = timing["scan_ms"] * 1e3 / max(timing["scan_launches"], 1)
-    algo_bytes = n_local * DIM * 2            # one pass over the fp16 shard per launch
+    # bytes the scan kernel must read per launch: one pass over the fp16 shard (N * 768 * 2), or over its
+    # int8 image (N * 768) when the int8 scan is in use -- the library reports which (rq_timing.scan_bytes)
+    algo_bytes = timing["scan_bytes"] // max(timing["scan_launches"], 1) if timing["scan_launches"] else n_local * DIM * (1 if int8_scan else 2)
     achieved = algo_bytes / (scan_us * 1e-6) / 1e9 if scan_us > 0 else 0.0
     # HBM traffic per launch is a PMC figure (rocprofv3 --pmc passes, tools/run_profiles.sh): it cannot be collected
     # inside this process, so the line carries the committed measurement and says where it comes from.
     traffic, traffic_source = None, None
-    for name in ("r02_pmc_scan.json", "r01_pmc_scan.json"):
+    for name in (("r02_pmc_scan8.json",) if int8_scan else ("r02_pmc_scan.json", "r01_pmc_scan.json")):
         pmc_path = os.path.join(ROOT, "profiles", name)
         if world == 1 and n_total == N_ROWS and os.path.exists(pmc_path):
             try:
@@ -316,14 +324,17 @@ def main() -> None:
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f16",
+        "dtype": "i8" if int8_scan else "f16",
         "data": "synthetic",
         "config": {"workload": f"{n_total}x{DIM} fp16 corpus, batch-{B} queries, top-{k}, cosine, exact (certified) results",
+                   "scan": ("int8 image of the fp16 shard (per-row scales, i8 matrix cores, exact int32 sums); candidates re-scored from the fp16 rows in fp64, "
+                            "certificate from the measured quantisation error") if int8_scan else "fp16 rows (f16 matrix cores); candidates re-scored in fp64",
                    "rows_per_gpu": n_local, "streams": len(streams), "pipeline": args.pipeline, "next_batch_hint": use_hint, "gather_every": GATHER_EVERY if use_comm else 0,
                    "parallelism": f"row-shard x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "kernel": "rq_scan_tail_kernel" if args.pipeline == 2 else "rq_scan_kernel",
                      "avg_launch_us": scan_us, "launches": timing["scan_launches"], "algorithmic_bytes_per_launch": algo_bytes,
+                     "scanned": "int8 image, 768 B per row" if int8_scan else "fp16 rows, 1536 B per row",
                      "measured": f"HIP events around every {max(1, args.event_stride)}-th scan launch of the timed region, on the stream it is launched on" if live_events else
                                  "HIP events around 24 single-stream launches right after the timed region (N > 1: no events inside it)",
                      "isolated": {"avg_launch_us": iso_us, "achieved": algo_bytes / (iso_us * 1e-6) / 1e9 if iso_us > 0 else 0.0,
@@ -337,6 +348,33 @@ def main() -> None:
         "host_phases": host_phases,
         "exact_scans": timing["exact_scans"],
     }
+
+    # ---- outside the timed region: the same loop over the fp16 rows (the scan of SURVEY 8d's byte count), for comparison ----
+    if world == 1 and int8_scan:
+        idx.set_option("scan8", 0)
+        idx.set_option("pipeline", args.pipeline)
+        nsteps = min(args.steps, 200)
+        for i in range(32):
+            step(i)
+        flush(); finish()
+        idx.set_option("profile", 1); idx.set_option("profile_stride", max(1, args.event_stride)); idx.reset_timing()
+        torch.cuda.synchronize()
+        tf = time.perf_counter()
+        for i in range(nsteps):
+            step(i)
+        flush(); finish()
+        ef = time.perf_counter() - tf
+        tm = idx.timing()
+        f_us = tm["scan_ms"] * 1e3 / max(tm["scan_launches"], 1)
+        f_bytes = n_local * DIM * 2
+        out["fp16_scan"] = {"value": nsteps * B / ef, "unit": "queries/s", "ms_per_step": ef / nsteps * 1e3, "steps": nsteps,
+                            "uncertified": int(status_np[:min(N_QUERY_BATCHES, nsteps)].sum()),
+                            "roofline": {"bound": "hbm", "achieved": f_bytes / (f_us * 1e-6) / 1e9 if f_us > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": (f_bytes / (f_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if f_us > 0 else 0.0,
+                                         "avg_launch_us": f_us, "algorithmic_bytes_per_launch": f_bytes},
+                            "note": "same loop with option scan8 = 0 (bench.py --scan fp16 times it as the main figure): every launch reads the fp16 rows"}
+        idx.set_option("profile", 0)
+        idx.set_option("scan8", {"auto": 1, "fp16": 0, "int8": 2}[args.scan])
 
     # ---- outside the timed region: recall vs the oracle, CPU baseline (rank 0, N = 1 only) ----------
     if world == 1:

@@ -296,7 +296,7 @@ extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     else if (s == "tail_stop") idx->tail_stop = (int)v;
     else if (s == "epi" || s == "fused_epi") idx->epi = (int)v != 0;   // selection form of the 64-query scan (default variant and fused launch): 1 = positions inside the scores, 0 = compare / select
     else if (s == "profile_legacy") idx->profile_legacy = (int)v != 0;   // time scans with hipEventRecord around the launch (round 1) instead of dispatch-attached events
-    else if (s == "scan8") { if (v < 0 || v > 2) return set_err(RQ_EINVAL, "scan8 must be 0, 1 or 2"); idx->scan8 = (int)v; }   // see run_pipeline
+    else if (s == "scan8") { if (v < 0 || v > 2) return set_err(RQ_EINVAL, "scan8 must be 0, 1 or 2"); idx->scan8 = (int)v; idx->scan8_suspended = false; idx->scan8_checked = idx->scan8_repaired = 0; }   // see run_pipeline
     else if (s == "thr_mult8") { if (!(v >= 1.05 && v <= 2.25)) return set_err(RQ_EINVAL, "thr_mult8 %g outside 1.05..2.25", v); idx->thr_mult8 = v; }
     else if (s == "use_hint") idx->use_hint = (int)v != 0;   // 0: rq_search_hint_next_device is ignored (A/B of the folded query preparation)
     else if (s == "poison_cand") idx->poison_cand = (int)v;   // test hook: candidate lists are filled with 0xff..ff keys before every tail
@@ -330,6 +330,7 @@ extern "C" double rq_get_option(const rq_index* idx, const char* name) {
     if (s == "scan8") return idx->scan8;
     if (s == "thr_mult8") return idx->thr_mult8;
     if (s == "scan8_row_err") return idx->x8_valid == idx->n && idx->x8 ? idx->max_e8 : -1.0;   // worst row's relative int8 error (-1: image not built)
+    if (s == "scan8_suspended") return idx->scan8_suspended ? 1.0 : 0.0;   // too many repairs behind the int8 scan (rq_search_fixup_device)
     if (s == "scan8_used") return (double)idx->scan8_used;   // searches that scanned the int8 image
     if (s == "hints_used") return (double)idx->hints_used;   // searches that found their queries prepared by the launch before them
     if (s == "max_sub_rel") return idx->max_sub_rel;   // largest share of a row's norm that sits in fp16-subnormal elements
@@ -508,7 +509,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     // batch) --, 2 = always): one pass of <= 64 queries over the int8 image of the shard, when its worst row quantises well
     // enough.  Its bound does not involve fp16 subnormals (the image is relative to each row's largest element).
     bool use8 = false;
-    if (idx->scan8 && nb >= 0 && 2 * (int64_t)nb < nbins && B <= 64 && !force_generic && idx->fast_tail && k <= RQ_FAST_MAX_K &&
+    if (idx->scan8 && !idx->scan8_suspended && nb >= 0 && 2 * (int64_t)nb < nbins && B <= 64 && !force_generic && idx->fast_tail && k <= RQ_FAST_MAX_K &&
         (idx->scan8 == 2 || idx->n >= RQ_SCAN8_MIN_ROWS)) {
         if (int r = ensure_x8(idx, s)) return r;
         use8 = idx->max_e8 <= RQ_SCAN8_MAX_ROW_ERR;
@@ -792,6 +793,16 @@ extern "C" int rq_search_fixup_device(rq_index* idx, const float* d_queries, int
     HIPCHK(hipStreamSynchronize(s));
     std::vector<int> bad;
     for (int q = 0; q < B; ++q) if (st[q] != 0) bad.push_back(q);
+    // The int8 scan bets that real errors stay well below its worst-case bound (threshold multiplier thr_mult8 < 2) and that
+    // few rows sit within that bound of the k-th score.  A shard / query mix on which either fails shows up here as repairs:
+    // beyond 1 in 16 checked queries (windows of 1024) the index goes back to the fp16 scan until "scan8" is set again.
+    if (idx->x8 && idx->scan8 && !idx->scan8_suspended && B <= 64) {
+        idx->scan8_checked += B; idx->scan8_repaired += (int64_t)bad.size();
+        if (idx->scan8_checked >= 1024) {
+            if (idx->scan8_repaired * 16 > idx->scan8_checked) idx->scan8_suspended = true;
+            idx->scan8_checked = idx->scan8_repaired = 0;
+        }
+    }
     if (bad.empty()) return 0;
     const int repaired = (int)bad.size();
     Workspace& w = idx->ctx[s].w[0];

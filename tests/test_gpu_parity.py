@@ -1325,6 +1325,21 @@ def test_int8_scan_on_hostile_shards_stays_exact():
     qc = xc[::1000][:48].astype(np.float32) + 0.05 * orc.synthetic_queries(48, 768, seed=9)
     _check(idx, xc, qc, 10)
     assert int(idx.get_option("scan8_used")) >= 1
+    # ... and when most queries need repairing (every query sits inside a cluster of ~900 near-identical scores), the index
+    # gives the int8 scan up after a window of 1024 checked queries; results stay exact throughout
+    assert idx.get_option("scan8_suspended") == 0.0
+    for rep in range(24):
+        qr = xc[rep::97][:64].astype(np.float32)
+        s_, r_ = idx.search(qr, 10)
+        if rep % 8 == 0:
+            gs, gr = orc.dense_topk(qr, xc, 10)
+            assert np.array_equal(r_, gr) and float(np.abs(s_ - gs).max()) <= SCORE_TOL
+    assert idx.get_option("scan8_suspended") == 1.0
+    used = int(idx.get_option("scan8_used"))
+    idx.search(qc, 10)
+    assert int(idx.get_option("scan8_used")) == used          # suspended: the fp16 scan
+    idx.set_option("scan8", 2)                                # setting the option again lifts the suspension
+    assert idx.get_option("scan8_suspended") == 0.0
     idx.close()
 
 

@@ -44,51 +44,61 @@ for logname in ("bench2", "bench20", "prof_bench", "prof_bench_1s"):
             d = json.loads(lines[-1])
             print(logname, "value", round(d["value"]), "ms/step", round(d["ms_per_step"], 4), "scan avg us", round(d["roofline"]["avg_launch_us"], 1), "frac", round(d["roofline"]["frac"], 3))
 
-# ---- matrix-core counters of the fused scan + tail launch -> achieved fp16 FLOP/s against the dense peak
+# The default bench launches two instantiations of the fused kernel: rq_scan_tail_kernel<true, 8, 2> (the int8 scan, the timed
+# region) and <true, 8, 1> (the fp16 scan, the comparison loop after it).  Each gets its own summary.
+VARIANTS = (("rq_scan_tail_kernel<true, 8, 2>", "8", 768, "SQ_INSTS_VALU_MFMA_MOPS_I8", "int8 image of the fp16 shard, i8 matrix cores"),
+            ("rq_scan_tail_kernel<true, 8, 1>", "", 1536, "SQ_INSTS_VALU_MFMA_MOPS_F16", "fp16 rows, f16 matrix cores"))
+
+def kernel_avg_us(sel):
+    if not ks:
+        return None
+    for r in csv.DictReader(open(ks)):
+        if sel in r["Name"]:
+            return float(r["AverageNs"]) / 1e3
+    return None
+
 mf = first("pmc_mfma/*/*counter_collection.csv")
-if mf:
+for sel, suffix, row_bytes, mops, what in VARIANTS:
+    if not mf:
+        break
     acc = {}
     for r in csv.DictReader(open(mf)):
-        if "rq_scan_tail" in r["Kernel_Name"]:
+        if sel in r["Kernel_Name"]:
             acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     mean = {k: sum(v) / len(v) for k, v in acc.items()}
-    dur_us = None
-    if ks:
-        for r in csv.DictReader(open(ks)):
-            if "rq_scan_tail" in r["Name"]:
-                dur_us = float(r["AverageNs"]) / 1e3
-    if "SQ_INSTS_VALU_MFMA_MOPS_F16" in mean and dur_us:
-        flop = mean["SQ_INSTS_VALU_MFMA_MOPS_F16"] * 512.0        # one MOP = 512 FLOP (a 16x16x32 MFMA = 16384 FLOP = 32 MOPs)
-        algo_flop = 2.0 * 64 * 1_000_000 * 768
+    dur_us = kernel_avg_us(sel)
+    if mops in mean and dur_us:
+        ops = mean[mops] * 512.0        # one MOP = 512 operations (a 16x16x32 f16 / 16x16x64 i8 MFMA = 16384 / 32768 operations)
+        algo = 2.0 * 64 * 1_000_000 * 768
         gui = mean.get("GRBM_GUI_ACTIVE", 0.0) / 8.0                # summed over the 8 XCDs
-        summ = {"kernel": "rq_scan_tail_kernel", "workload": "1000000x768 fp16 corpus, 64 queries per launch",
+        peak = 2500.0 if row_bytes == 1536 else 5000.0             # dense fp16 TFLOP/s / dense int8 TOP/s (MI355X_MICROARCH.md)
+        summ = {"kernel": sel, "workload": f"1000000x768 fp16 corpus ({what}), 64 queries per launch",
                 "counters_mean_per_launch": mean, "launches": len(next(iter(acc.values()))),
                 "avg_launch_us_from_kernel_stats": dur_us,
-                "mfma_flop_per_launch": flop, "algorithmic_flop_per_launch": algo_flop, "flop_over_algorithmic": flop / algo_flop,
-                "achieved_TFLOPs": flop / (dur_us * 1e-6) / 1e12, "dense_fp16_peak_TFLOPs": 2500.0,
-                "mfma_frac_of_peak": flop / (dur_us * 1e-6) / 1e12 / 2500.0,
+                "mfma_ops_per_launch": ops, "algorithmic_ops_per_launch": algo, "ops_over_algorithmic": ops / algo,
+                "achieved_Tops": ops / (dur_us * 1e-6) / 1e12, "dense_peak_Tops": peak,
+                "mfma_frac_of_peak": ops / (dur_us * 1e-6) / 1e12 / peak,
                 "mfma_busy_frac": (mean.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * gui)) if gui else None,
-                "note": "SQ_VALU_MFMA_BUSY_CYCLES counts 16 cycles per v_mfma_f32_16x16x32_f16, summed over the 1024 SIMDs; GRBM_GUI_ACTIVE / 8 = "
-                        "shader cycles of the launch.  The kernel is HBM-bound (64 FLOP per corpus byte against a machine balance of ~310): "
-                        "the matrix cores are the means not to be ALU-bound, not the roofline."}
-        json.dump(summ, open(os.path.join(out, f"{tag}_pmc_mfma.json"), "w"), indent=1)
-        print("mfma:", {k: summ[k] for k in ("achieved_TFLOPs", "mfma_frac_of_peak", "mfma_busy_frac", "flop_over_algorithmic")})
+                "note": "SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs; GRBM_GUI_ACTIVE / 8 = shader cycles of the launch.  The kernel is "
+                        "HBM-bound: the matrix cores are the means not to be ALU-bound, not the roofline."}
+        json.dump(summ, open(os.path.join(out, f"{tag}_pmc_mfma{suffix}.json"), "w"), indent=1)
+        print("mfma", sel, {k: summ[k] for k in ("achieved_Tops", "mfma_frac_of_peak", "mfma_busy_frac", "ops_over_algorithmic")})
 
-pmc = {}
-for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-    f = first(f"{name}/*/*counter_collection.csv")
-    if not f:
+for sel, suffix, row_bytes, mops, what in VARIANTS:
+    pmc = {}
+    for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        f = first(f"{name}/*/*counter_collection.csv")
+        if not f:
+            continue
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and sel in r["Kernel_Name"]]
+        if vals:
+            pmc[counter] = {"launches": len(vals), "mean": sum(vals) / len(vals), "min": min(vals), "max": max(vals), "unit": "KiB (rocprofv3 derived counter)"}
+    if "FETCH_SIZE" not in pmc:
         continue
-    recs = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
-    fused = [r for r in recs if "rq_scan_tail" in r["Kernel_Name"]]     # the bench default: scan + previous batch's tail
-    vals = [float(r["Counter_Value"]) for r in (fused or [r for r in recs if "rq_scan" in r["Kernel_Name"]])]
-    pmc_kernel = "rq_scan_tail_kernel" if fused else "rq_scan_kernel"
-    pmc[counter] = {"launches": len(vals), "mean": sum(vals) / len(vals), "min": min(vals), "max": max(vals), "unit": "KiB (rocprofv3 derived counter)"}
-if "FETCH_SIZE" in pmc:
     fetch = pmc["FETCH_SIZE"]["mean"] * 1024
     write = pmc.get("WRITE_SIZE", {"mean": 0.0})["mean"] * 1024
     summary = {
-        "kernel": pmc_kernel, "workload": "1000000x768 fp16 corpus, 64 queries per launch",
+        "kernel": sel, "workload": f"1000000x768 fp16 corpus ({what}), 64 queries per launch",
         "counters": pmc,
         "correction": "MI355X_MICROARCH.md 'HBM': on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced "
                       "streaming read (16 B/lane, global_load and LDS-DMA alike) -> read bytes = 2 * FETCH_SIZE * 1024; "
@@ -96,8 +106,8 @@ if "FETCH_SIZE" in pmc:
         "hbm_read_bytes_per_launch": 2 * fetch,
         "hbm_write_bytes_per_launch": write,
         "hbm_bytes_per_launch": 2 * fetch + write,
-        "algorithmic_bytes_per_launch": 1_000_000 * 768 * 2,
+        "algorithmic_bytes_per_launch": 1_000_000 * row_bytes,
     }
     summary["traffic_over_algorithmic"] = summary["hbm_bytes_per_launch"] / summary["algorithmic_bytes_per_launch"]
-    json.dump(summary, open(os.path.join(out, f"{tag}_pmc_scan.json"), "w"), indent=1)
-    print("pmc:", {k: summary[k] for k in ("hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch", "traffic_over_algorithmic")})
+    json.dump(summary, open(os.path.join(out, f"{tag}_pmc_scan{suffix}.json"), "w"), indent=1)
+    print("pmc", sel, {k: summary[k] for k in ("hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch", "traffic_over_algorithmic")})
