@@ -30,6 +30,7 @@ def loop(steps):
 for rep in range(2):
     for opts in sets:
         pairs = [o.split("=") for o in opts.split(",") if o]
+        idx.set_option("scan8", 1); idx.set_option("thr_mult8", 1.25); idx.set_option("tail_stop", 0)   # defaults, then the set
         for name, v in pairs:
             idx.set_option(name, float(v))
         idx.set_option("profile", 0)
@@ -39,6 +40,6 @@ for rep in range(2):
         t = idx.timing()
         unc = int(sum(int(o[2].sum()) for o in outs))
         print(f"{opts:40s}: {dt * 1e6:7.1f} us/batch  launch {t['scan_ms'] / max(t['scan_launches'], 1) * 1e3:6.1f} us  uncertified {unc}", flush=True)
-        idx.set_option("tail_stop", 0); idx.set_option("thr_mult8", 1.25)
+        idx.set_option("tail_stop", 0)
         loop(16)
 idx.close()
