@@ -424,7 +424,7 @@ static int ensure_x8(rq_index* idx, hipStream_t s) {
 // the shard's share of the int8 scan's bound (unit-query units; the query's own share is added per query by the tail):
 // worst row + the fp32 steps between the exact int32 sum and the bin record (two scale products, two 6-bit truncations)
 static inline float scan8_eps(const rq_index* idx) { return (float)(idx->max_e8 * 1.000001 + 2e-5); }
-#define RQ_SCAN8_MIN_ROWS 350000
+#define RQ_SCAN8_MIN_ROWS 160000
 #define RQ_SCAN8_MAX_ROW_ERR 0.03   // beyond that the candidate sets stop being small: such a shard keeps the fp16 scan
 
 static int fill_empty(int B, int k, float* d_scores, int64_t* d_rows, uint64_t* d_keys, int* d_status, hipStream_t s) {
@@ -505,8 +505,8 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     // tiny shards (fewer than two bins per wanted bin): the approximate pass cannot narrow anything down
     // ... and shards whose rows keep so much of their norm in fp16-subnormal elements that the scan's scores say nothing
     // int8 scan ("scan8": 0 = never, 1 = shards of RQ_SCAN8_MIN_ROWS rows and more -- below that the scan is too short for
-    // the saving to outweigh the larger candidate sets the looser bound brings (measured at 125k rows: 60 vs 52 us per
-    // batch) --, 2 = always): one pass of <= 64 queries over the int8 image of the shard, when its worst row quantises well
+    // the saving to outweigh the larger candidate sets the looser bound brings (fused two-stream loop, us per batch int8 / fp16:
+    // 250k rows 38.6 / 64.4, 125k rows 29.4 / 28.9) --, 2 = always): one pass of <= 64 queries over the int8 image of the shard, when its worst row quantises well
     // enough.  Its bound does not involve fp16 subnormals (the image is relative to each row's largest element).
     bool use8 = false;
     if (idx->scan8 && !idx->scan8_suspended && nb >= 0 && 2 * (int64_t)nb < nbins && B <= 64 && !force_generic && idx->fast_tail && k <= RQ_FAST_MAX_K &&
