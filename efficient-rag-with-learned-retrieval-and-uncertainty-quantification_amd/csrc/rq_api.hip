@@ -298,6 +298,7 @@ extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     else if (s == "profile_legacy") idx->profile_legacy = (int)v != 0;   // time scans with hipEventRecord around the launch (round 1) instead of dispatch-attached events
     else if (s == "scan8") { if (v < 0 || v > 2) return set_err(RQ_EINVAL, "scan8 must be 0, 1 or 2"); idx->scan8 = (int)v; idx->scan8_suspended = false; idx->scan8_checked = idx->scan8_repaired = 0; }   // see run_pipeline
     else if (s == "thr_mult8") { if (!(v >= 1.05 && v <= 2.25)) return set_err(RQ_EINVAL, "thr_mult8 %g outside 1.05..2.25", v); idx->thr_mult8 = v; }
+    else if (s == "tail_local") idx->tail_local = (int)v != 0;   // A/B: 0 = every re-scored row's key goes to the query's global list
     else if (s == "use_hint") idx->use_hint = (int)v != 0;   // 0: rq_search_hint_next_device is ignored (A/B of the folded query preparation)
     else if (s == "poison_cand") idx->poison_cand = (int)v;   // test hook: candidate lists are filled with 0xff..ff keys before every tail
     else return set_err(RQ_EINVAL, "unknown option '%s'", name);
@@ -692,6 +693,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             ta.eps = use8 ? scan8_eps(idx) : scan_eps(idx, metric);
             ta.qeps = use8 ? qeps8 : nullptr;
             ta.thr_mult = use8 ? (float)idx->thr_mult8 : 2.25f;
+            ta.local_topk = idx->tail_local;
             ta.max_row_norm = (float)(idx->max_row_norm * (1.0 + 1e-6)); ta.row_offset = idx->row_offset;
             ta.cand = w.cand; ta.rowcount = w.rowcount; ta.done = w.done; ta.ovf = w.ovf;
             ta.out_scores = d_scores; ta.out_rows = d_rows; ta.out_keys = d_keys; ta.out_status = d_status;

@@ -44,13 +44,67 @@ __device__ __forceinline__ void rq_emit(const RqFinalCore& a, int rank, uint64_t
     if (a.out_keys) a.out_keys[rank] = rq_make_key(s, (uint32_t)grow);
 }
 
+// The `want` largest of up to 4096 keys held in registers (16 per thread, 0 = empty; non-empty keys are unique), all 256
+// threads: a radix select over the whole workgroup (per round 16 ballots per wave, one LDS word per wave, one barrier).  The
+// keys of one query share their leading bits (scores within a few percent of each other): those rounds are skipped -- one
+// reduction of the keys' OR and AND finds the first bit they differ in -- and the select stops at the first threshold that
+// exactly `have` keys reach.  Returns have = min(want, non-empty keys); L.skeys[0 .. have) then hold the winners, unordered.
+__device__ __forceinline__ int rq_select_winners(const uint64_t (&key)[16], const int want, RqFinalLds& L) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int round = 0;
+    auto count_ge = [&](uint64_t t) -> int {
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c += __popcll(__ballot(key[i] >= t));
+        if (lane == 0) L.wbest[round & 1][wave] = (uint64_t)c;
+        __syncthreads();
+        const int tot = (int)(L.wbest[round & 1][0] + L.wbest[round & 1][1] + L.wbest[round & 1][2] + L.wbest[round & 1][3]);
+        ++round;
+        return tot;   // uniform over the workgroup
+    };
+    const int nzt = count_ge(1);                         // non-empty keys
+    const int have = nzt < want ? nzt : want;
+    uint64_t prefix = 1;                                 // have == nzt: every non-empty key is a winner
+    if (nzt > have) {                                    // the have-th largest key: the largest t with count(key >= t) >= have
+        uint64_t kor = 0, kand = ~0ull;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) if (key[i] != 0) { kor |= key[i]; kand &= key[i]; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { kor |= __shfl_xor(kor, off, 64); kand &= __shfl_xor(kand, off, 64); }
+        if (lane == 0) { L.wbest[round & 1][wave] = kor; L.skeys[wave] = kand; }
+        __syncthreads();
+        kor = L.wbest[round & 1][0] | L.wbest[round & 1][1] | L.wbest[round & 1][2] | L.wbest[round & 1][3];
+        kand = L.skeys[0] & L.skeys[1] & L.skeys[2] & L.skeys[3];
+        ++round;
+        const uint64_t diff = kor ^ kand;                // != 0: the keys are unique and there are at least two
+        const int top = 63 - __builtin_clzll(diff | 1ull);   // highest bit in which two keys differ
+        prefix = top == 63 ? 0 : (kand >> (top + 1)) << (top + 1);
+        for (int bit = top; bit >= 0; --bit) {
+            const uint64_t t = prefix | (1ull << bit);
+            const int c = count_ge(t);                   // uniform
+            if (c >= have) {
+                prefix = t;
+                if (c == have) break;                    // exactly the winners are >= t: the remaining bits cannot change the set
+            }
+        }
+    }
+    // keys are unique, so exactly `have` keys are >= prefix
+    if (tid == 0) L.snz = 0;
+    __syncthreads();                                     // (also: every thread is past its reads of L.skeys[0..3] above)
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (key[i] != 0 && key[i] >= prefix) L.skeys[atomicAdd(&L.snz, 1)] = key[i];
+    __syncthreads();
+    return have;
+}
+
 // total: keys that wanted a slot (may exceed RQ_CAND_CAP = overflow); overflow: any other overflow seen for this query;
 // T: every row that was NOT re-scored has approximate score < T;  qn: fp64 norm of the query.
 // The keys were published by other workgroups of the SAME launch with sc1 (write-through) stores and a ticket; the caller
 // (rq_tail_body.h, section D) has run an agent-scope acquire + workgroup barrier before this point, and every load of the
 // keys is an sc1 load (relaxed agent-scope atomic load) besides.
 __device__ __forceinline__ void rq_final_body(const RqFinalCore& a, int total, int overflow, float T, double qn, RqFinalLds& L) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int64_t kk = a.k < a.n_rows ? a.k : a.n_rows;
     if (qn == 0.0) {   // every score is exactly 0: rows 0 .. kk-1 (score desc, row asc)
         for (int j = tid; j < a.k; j += 256) {
@@ -93,53 +147,7 @@ __device__ __forceinline__ void rq_final_body(const RqFinalCore& a, int total, i
             const int j = i * 256 + tid;
             key[i] = j < n ? __hip_atomic_load(a.cand + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
         }
-        // workgroup-wide count of keys >= t (t != 0): 16 ballots per wave, one LDS word per wave, one barrier
-        int round = 0;
-        auto count_ge = [&](uint64_t t) -> int {
-            int c = 0;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) c += __popcll(__ballot(key[i] >= t));
-            if (lane == 0) L.wbest[round & 1][wave] = (uint64_t)c;
-            __syncthreads();
-            const int tot = (int)(L.wbest[round & 1][0] + L.wbest[round & 1][1] + L.wbest[round & 1][2] + L.wbest[round & 1][3]);
-            ++round;
-            return tot;   // uniform over the workgroup
-        };
-        const int nzt = count_ge(1);                         // non-empty keys (0 = a row beyond the shard's end)
-        have = nzt < a.k ? nzt : a.k;
-        uint64_t prefix = 1;                                 // have == nzt: every non-empty key is a winner
-        if (nzt > have) {                                    // the have-th largest key: the largest t with count(key >= t) >= have
-            // the keys of one query share their leading bits (scores within a few percent of each other): those rounds are
-            // skipped -- one reduction of the keys' OR and AND finds the first bit they differ in
-            uint64_t kor = 0, kand = ~0ull;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) if (key[i] != 0) { kor |= key[i]; kand &= key[i]; }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) { kor |= __shfl_xor(kor, off, 64); kand &= __shfl_xor(kand, off, 64); }
-            if (lane == 0) { L.wbest[round & 1][wave] = kor; L.skeys[wave] = kand; }
-            __syncthreads();
-            kor = L.wbest[round & 1][0] | L.wbest[round & 1][1] | L.wbest[round & 1][2] | L.wbest[round & 1][3];
-            kand = L.skeys[0] & L.skeys[1] & L.skeys[2] & L.skeys[3];
-            ++round;
-            const uint64_t diff = kor ^ kand;                // != 0: the keys are unique and there are at least two
-            const int top = 63 - __builtin_clzll(diff | 1ull);   // highest bit in which two keys differ
-            prefix = top == 63 ? 0 : (kand >> (top + 1)) << (top + 1);
-            for (int bit = top; bit >= 0; --bit) {
-                const uint64_t t = prefix | (1ull << bit);
-                const int c = count_ge(t);                   // uniform
-                if (c >= have) {
-                    prefix = t;
-                    if (c == have) break;                    // exactly the winners are >= t: the remaining bits cannot change the set
-                }
-            }
-        }
-        // keys are unique, so exactly `have` keys are >= prefix: compact them, then rank them among themselves
-        if (tid == 0) L.snz = 0;
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (key[i] != 0 && key[i] >= prefix) L.skeys[atomicAdd(&L.snz, 1)] = key[i];
-        __syncthreads();
+        have = rq_select_winners(key, a.k, L);           // winners compacted into L.skeys[0 .. have): rank them among themselves
         for (int s2 = tid; s2 < have; s2 += 256) {
             const uint64_t mine = L.skeys[s2];
             int r = 0;

@@ -119,6 +119,7 @@ struct RqTailArgs {
     int* rowcount; int* done; int* ovf;            // [B] each, zero before the launch, reset by the kernel
     float* out_scores; int64_t* out_rows; uint64_t* out_keys; int* out_status;
     const float* qeps;                             // per query error share e_q (int8 scan): bound = e_q (1 + eps) + eps; null = eps alone
+    int local_topk;                                // 1: a workgroup with more than k row jobs publishes only its own k best keys (rq_tail_body.h)
     float thr_mult;                                // threshold T = P - thr_mult * bound (2.25 always certifies; less = fewer candidates, may not)
     unsigned long long* dbg;                       // development: per-workgroup (start, end) wall-clock stamps of the fused launch, or null
     int stop_after;                                // development: 0 = full kernel, 1..4 = return after phase A..D

@@ -131,8 +131,13 @@ __device__ __forceinline__ void rq_tail_body(const RqTailArgs& a, const int chun
     const int nh = nhit_s;
     const int njob_all = njob_s;
     const int njob = njob_all < RQ_TAIL_JOBCAP ? njob_all : RQ_TAIL_JOBCAP;
+    // A row that is not among the k best of THIS workgroup's candidates cannot be among the k best of the query: with more
+    // than k jobs the exact keys stay in LDS, the workgroup selects its own k best and publishes only those.  The query's
+    // list then holds at most k keys per workgroup (the final ranks 40 keys instead of the 60-500 the int8 scan's looser
+    // bound collects at k = 10, and lists that used to overflow RQ_CAND_CAP -- clustered corpora -- no longer do).
+    const bool local = a.local_topk && njob_all > a.k && njob_all <= RQ_TAIL_JOBCAP;
     if (tid == 0) {
-        base_s = njob_all ? atomicAdd(&a.rowcount[q], njob_all) : 0;
+        base_s = njob_all ? atomicAdd(&a.rowcount[q], local ? a.k : njob_all) : 0;
         if (nh > RQ_TAIL_HITCAP || njob_all > RQ_TAIL_JOBCAP) atomicOr(&a.ovf[q], 1);
     }
     // fp64 norm of the query (only workgroups with jobs, and later the last one, need it)
@@ -165,10 +170,12 @@ __device__ __forceinline__ void rq_tail_body(const RqTailArgs& a, const int chun
             int64_t rows[2];
             double rn[2];
             int pos[2];
+            bool lv[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int jb = j0 + u * 4 + rloc;
                 const bool live = jb < njob;
+                lv[u] = live;
                 const int job = jobs[live ? jb : 0];
                 pos[u] = (live && base + jb < RQ_CAND_CAP) ? base + jb : -1;   // -1: nothing stored (padding or list full)
                 rows[u] = (int64_t)hits[job >> 6] * RQ_BIN_ROWS + (job & 63);
@@ -193,7 +200,7 @@ __device__ __forceinline__ void rq_tail_body(const RqTailArgs& a, const int chun
                 double d = dot[u];
 #pragma unroll
                 for (int off = 8; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
-                if (sub == 0 && pos[u] >= 0) {
+                if (sub == 0 && (local ? lv[u] : pos[u] >= 0)) {
                     uint64_t key = 0;                                       // stays 0 for a row beyond the shard's end
                     if (rows[u] < a.n_rows) {
                         double sc = d;
@@ -201,9 +208,42 @@ __device__ __forceinline__ void rq_tail_body(const RqTailArgs& a, const int chun
                         key = rq_make_key(rq_sanitize((float)sc), (uint32_t)rows[u]);
                     }
                     // write-through (sc1) store: visible to the last workgroup without a release fence
-                    __hip_atomic_store(&out[pos[u]], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (local) L.flds.skeys[j0 + u * 4 + rloc] = key;
+                    else __hip_atomic_store(&out[pos[u]], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
+        }
+        if (local) {   // uniform over the workgroup
+            __syncthreads();
+            RqFinalLds& F = L.flds;
+            const int want = a.k;
+            int have;
+            if (njob <= 256) {
+                // one key per thread, ranked against all others through LDS; non-empty keys are unique (they carry their row)
+                const uint64_t mine = tid < njob ? F.skeys[tid] : 0;
+                if (tid == 0) F.snz = 0;
+                __syncthreads();
+                int r = 0;
+                if (mine != 0) {
+#pragma unroll 4
+                    for (int j = 0; j < njob; ++j) r += F.skeys[j] > mine ? 1 : 0;
+                    atomicAdd(&F.snz, 1);
+                    if (r < want && base + r < RQ_CAND_CAP) __hip_atomic_store(&out[base + r], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+                have = F.snz < want ? F.snz : want;
+            } else {
+                uint64_t key[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { const int j = i * 256 + tid; key[i] = j < njob ? F.skeys[j] : 0; }
+                __syncthreads();                                  // every key is in registers before the select re-uses the buffer
+                have = rq_select_winners(key, want, F);
+                for (int j = tid; j < have; j += 256)
+                    if (base + j < RQ_CAND_CAP) __hip_atomic_store(&out[base + j], F.skeys[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // the slots this workgroup reserved but has no key for (rows beyond the shard's end among its jobs): empty
+            for (int j = have + tid; j < want; j += 256)
+                if (base + j < RQ_CAND_CAP) __hip_atomic_store(&out[base + j], (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (a.stop_after == 3) return;

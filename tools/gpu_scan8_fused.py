@@ -2,8 +2,11 @@
 usage: python tools/gpu_scan8_fused.py "name=value,..;name=value,.." (one run per ';'-separated option set)"""
 import sys, time
 import numpy as np, torch
+import os, pathlib
 sys.path.insert(0, ".")
 from rag_uq_amd import _native as nat
+if os.environ.get("RQ_AB_LIB"):          # development: time another build of the library (e.g. tools/ab/librq_hip_old.so)
+    nat.LIB_PATH = pathlib.Path(os.environ["RQ_AB_LIB"]).resolve()
 
 n, k = 1_000_000, 10
 sets = (sys.argv[1] if len(sys.argv) > 1 else "thr_mult8=1.25").split(";")
