@@ -425,7 +425,10 @@ static int ensure_x8(rq_index* idx, hipStream_t s) {
 // the shard's share of the int8 scan's bound (unit-query units; the query's own share is added per query by the tail):
 // worst row + the fp32 steps between the exact int32 sum and the bin record (two scale products, two 6-bit truncations)
 static inline float scan8_eps(const rq_index* idx) { return (float)(idx->max_e8 * 1.000001 + 2e-5); }
-#define RQ_SCAN8_MIN_ROWS 160000
+#define RQ_SCAN8_MIN_ROWS 100000
+// ... and k <= 32: at k = 100 the candidate sets of the looser bound make the launch tail-bound on Gaussian data (181 vs 239 us)
+// and overflow the lists on document-structured corpora (runs of similar passages: every query repaired)
+#define RQ_SCAN8_AUTO_MAX_K 32
 #define RQ_SCAN8_MAX_ROW_ERR 0.03   // beyond that the candidate sets stop being small: such a shard keeps the fp16 scan
 
 static int fill_empty(int B, int k, float* d_scores, int64_t* d_rows, uint64_t* d_keys, int* d_status, hipStream_t s) {
@@ -505,13 +508,13 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     const int64_t nbins = nquads;   // bin = quad
     // tiny shards (fewer than two bins per wanted bin): the approximate pass cannot narrow anything down
     // ... and shards whose rows keep so much of their norm in fp16-subnormal elements that the scan's scores say nothing
-    // int8 scan ("scan8": 0 = never, 1 = shards of RQ_SCAN8_MIN_ROWS rows and more -- below that the scan is too short for
+    // int8 scan ("scan8": 0 = never, 1 = k <= RQ_SCAN8_AUTO_MAX_K on shards of RQ_SCAN8_MIN_ROWS rows and more -- below that the scan is too short for
     // the saving to outweigh the larger candidate sets the looser bound brings (fused two-stream loop, us per batch int8 / fp16:
-    // 250k rows 38.6 / 64.4, 125k rows 29.4 / 28.9) --, 2 = always): one pass of <= 64 queries over the int8 image of the shard, when its worst row quantises well
+    // 250k rows 35.0 / 59.8, 125k rows 25.0 / 29.0; shorter scans are bound by launch latencies) --, 2 = always): one pass of <= 64 queries over the int8 image of the shard, when its worst row quantises well
     // enough.  Its bound does not involve fp16 subnormals (the image is relative to each row's largest element).
     bool use8 = false;
     if (idx->scan8 && !idx->scan8_suspended && nb >= 0 && 2 * (int64_t)nb < nbins && B <= 64 && !force_generic && idx->fast_tail && k <= RQ_FAST_MAX_K &&
-        (idx->scan8 == 2 || idx->n >= RQ_SCAN8_MIN_ROWS)) {
+        (idx->scan8 == 2 || (idx->n >= RQ_SCAN8_MIN_ROWS && k <= RQ_SCAN8_AUTO_MAX_K))) {
         if (int r = ensure_x8(idx, s)) return r;
         use8 = idx->max_e8 <= RQ_SCAN8_MAX_ROW_ERR;
     }

@@ -129,13 +129,14 @@ int rq_merge_keys_device(const uint64_t* d_keys_in, int n_per_query, int B, int 
  * "epi" (selection form of the 64-query scan: 1 = row positions inside the scores, 0 = compare / select),
  * "use_hint" (0: rq_search_hint_next_device is ignored),
  * "scan8" (calls of <= 64 queries may scan an int8 image of the shard instead of its fp16 rows -- half the bytes per pass;
- *   candidates are still re-scored from the fp16 rows in fp64, so results do not change: 0 = never, 1 = on shards of 350 000
- *   rows and more (default), 2 = always.  The image (+768 B per row) is built by the first search that wants it; a shard whose
+ *   candidates are still re-scored from the fp16 rows in fp64, so results do not change: 0 = never, 1 = for k <= 32 on shards of
+ *   100 000 rows and more (default), 2 = always.  The image (+768 B per row) is built by the first search that wants it; a shard whose
  *   worst row quantises with more than 3 % relative error keeps the fp16 scan),
  * "thr_mult8" (1.05 .. 2.25, default 1.25: candidate threshold of the int8 scan in units of its worst-case error bound; 2.25
  *   certifies by construction, smaller values re-score fewer rows and leave the rare query whose errors add up to the
  *   repair path of rq_search_fixup_device; when more than 1 in 16 checked queries need repair the index stops using the
  *   image until "scan8" is set again),
+ * "tail_local" (A/B hook, default 1: a tail workgroup with more than k re-scored rows publishes only its own k best keys),
  * "poison_cand" (test hook: candidate lists are filled with 0xff..ff keys before every tail).
  * Read-only: "scan8_used" (searches that scanned the int8 image), "scan8_row_err" (worst row's relative int8 error, -1 = image
  * not built), "scan8_suspended", "hints_used" (searches that found their queries prepared, see rq_search_hint_next_device), "max_row_norm", "max_sub_rel" / "max_sub_abs" (largest share of a stored row that sits in fp16-subnormal elements,

@@ -600,7 +600,7 @@ def _device_corpus(idx, n, seed0, chunk=125_000):
         del x
 
 
-@pytest.mark.parametrize("n,expect_nv,scan8", [(1_000_000, 8, 0), (300_000, 4, 0), (1_000_000, 8, 1)])
+@pytest.mark.parametrize("n,expect_nv,scan8", [(1_000_000, 8, 0), (300_000, 4, 0), (1_000_000, 8, 2)])
 def test_fused_headline_instantiation_matches_oracle(n, expect_nv, scan8):
     """The kernel bench.py times: rq_scan_tail_kernel<NT = true, NV> (option pipeline = 2: the tail of batch i rides in
     the scan launch of batch i + 1), one stream, consecutive 64-query batches -- at the headline size (1M rows: non-temporal
@@ -620,7 +620,7 @@ def test_fused_headline_instantiation_matches_oracle(n, expect_nv, scan8):
     assert n * 1536 > (208 << 20)                                          # -> non-temporal corpus loads (csrc/rq_api.hip)
     idx.set_option("pipeline", 2)
     idx.set_option("poison_cand", 1)
-    idx.set_option("scan8", scan8)            # 1: the int8 scan (rq_scan_tail_kernel<..., 2>), what bench.py times by default
+    idx.set_option("scan8", scan8)            # 2: the int8 scan (rq_scan_tail_kernel<..., 2>, what bench.py times by default) for every k of the plan
     st = torch.cuda.Stream(device=dev)
     plan = [(10, 0), (10, 0), (100, 0), (100, 0), (10, 1), (10, 0), (10, 0)]          # (k, metric) of consecutive calls
     qs = [orc.synthetic_queries(64, 768, seed=4321 + i) * (3.0 if m == 1 else 1.0) for i, (k, m) in enumerate(plan)]
@@ -1251,7 +1251,7 @@ def test_int8_scan_matches_oracle_100k(corpus100k):
         _check(idx, x16, orc.synthetic_queries(130, 768, seed=8), 10)      # more than 64 queries: the fp16 passes, unchanged
         assert int(idx.get_option("scan8_used")) == before + 6
     finally:
-        idx.set_option("scan8", 0)
+        idx.set_option("scan8", 1)
 
 
 def _planted_outlier_rows(n, seed):
@@ -1344,7 +1344,7 @@ def test_int8_scan_on_hostile_shards_stays_exact():
 
 
 def test_int8_scan_automatic_rule_and_options():
-    """scan8 = 1 uses the int8 image only on shards of 160 000 rows and more; thr_mult8 is validated; the always-certifying
+    """scan8 = 1 uses the int8 image only for k <= 32 on shards of 100 000 rows and more; thr_mult8 is validated; the always-certifying
     multiplier 2.25 gives the same rows."""
     import torch
     idx = nat.NativeIndex(768, 0)
@@ -1353,6 +1353,8 @@ def test_int8_scan_automatic_rule_and_options():
     q = orc.synthetic_queries(8, 768, seed=12)
     idx.set_option("scan8", 1)
     _check(idx, x16, q, 10)
+    assert int(idx.get_option("scan8_used")) == 1
+    _check(idx, x16, q, 100)                   # the automatic rule stops at k = 32
     assert int(idx.get_option("scan8_used")) == 1
     idx.set_option("thr_mult8", 2.25)
     _check(idx, x16, q, 10)
@@ -1369,3 +1371,36 @@ def test_int8_scan_automatic_rule_and_options():
     _check(small, xs, q, 10)
     assert int(small.get_option("scan8_used")) == 0 and small.get_option("scan8_row_err") == -1.0     # image never built
     small.close()
+
+
+def test_int8_scan_bin_maxima_within_its_measured_bound():
+    """The int8 scan's scores (read back as per-bin maxima, rq_debug_pooled) against the exact per-bin maxima of the oracle:
+    |approx - exact| <= e_q + (1 + e_q) e_rows + 2e-5 with e_rows the library's measured worst row (option scan8_row_err) and
+    e_q the query's own quantisation error, recomputed here in numpy -- the bound the certificate uses.  Also
+    checks that the errors actually seen are several times smaller, which is what the threshold multiplier 1.25 relies on.
+    Validates the i8 MFMA operand layout, the shared stage geometry and the per-row / per-query scales."""
+    n, B = 40_033, 64
+    x16 = orc.synthetic_corpus(n, 768, seed=71)
+    x16[5] = 0
+    q = orc.synthetic_queries(B, 768, seed=72) * 3.0
+    q[3] = x16[100].astype(np.float32)
+    q[4] = 0; q[4, 17] = 2.0                                          # one-hot query: quantises exactly
+    idx = nat.NativeIndex(768, 0)
+    idx.add_f16(x16)
+    idx.set_option("scan8", 2)
+    worst = _pooled_error(idx, x16, q, range(B))
+    assert int(idx.get_option("scan8_used")) == 1
+    e_rows = idx.get_option("scan8_row_err")
+    sq = np.abs(q).max(axis=1, keepdims=True) / 127.0
+    e_q = np.linalg.norm(q - sq * np.rint(q / sq), axis=1) / np.linalg.norm(q, axis=1)
+    assert e_q[4] < 1e-6 and 0.005 < e_q.max() < 0.012
+    bound = float(e_q.max() + (1 + e_q.max()) * e_rows + 2e-5)
+    assert worst <= bound, (worst, bound)
+    assert worst <= 0.3 * bound, f"observed error {worst} against a bound of {bound}: the int8 threshold assumes a wide margin"
+    # the library's own view of the rows' error agrees with numpy's
+    x = x16.astype(np.float64)
+    sr = np.abs(x).max(axis=1, keepdims=True) / 127.0
+    with np.errstate(invalid="ignore", divide="ignore"):
+        er = np.linalg.norm(x - sr * np.rint(x / np.where(sr > 0, sr, 1)), axis=1) / np.linalg.norm(x, axis=1)
+    assert e_rows == pytest.approx(float(np.nanmax(er)), rel=1e-3)
+    idx.close()
