@@ -59,6 +59,11 @@ _SIGNATURES = {
     "rq_search_fixup_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "rq_search_flush_device": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rq_nb_rope_table_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
+    "rq_nb_attention_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "rq_nb_add_layernorm_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p]),
+    "rq_nb_swiglu_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "rq_nb_mean_pool_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "rq_search_hint_next_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "rq_stream_release": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rq_merge_keys_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -269,6 +274,30 @@ class NativeIndex:
         if not h:
             raise RqError(f"rq_load({path}): {last_error()}")
         return cls(0, devs[0], _handle=h, devices=devs)
+
+
+# -- encoder pieces (include/rq.h "encoder pieces", csrc/rq_encoder.hip): torch tensors or raw device addresses -------------
+def nb_rope_table(rope, seq: int, rope_theta: float, stream: int = 0) -> None:
+    _check(load_library().rq_nb_rope_table_f32(_ptr(rope), int(seq), float(rope_theta), C.c_void_p(stream)), "rq_nb_rope_table_f32")
+
+
+def nb_attention(qkv, lengths, rope, ctx, batch: int, seq: int, heads: int, stream: int = 0) -> None:
+    _check(load_library().rq_nb_attention_f16(_ptr(qkv), _ptr(lengths), _ptr(rope), _ptr(ctx), int(batch), int(seq), int(heads),
+                                              C.c_void_p(stream)), "rq_nb_attention_f16")
+
+
+def nb_add_layernorm(x, res, gamma, beta, out, rows: int, width: int, eps: float, stream: int = 0) -> None:
+    _check(load_library().rq_nb_add_layernorm_f16(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(out), int(rows), int(width), float(eps),
+                                                  C.c_void_p(stream)), "rq_nb_add_layernorm_f16")
+
+
+def nb_swiglu(gate_up, out, rows: int, inter: int, stream: int = 0) -> None:
+    _check(load_library().rq_nb_swiglu_f16(_ptr(gate_up), _ptr(out), int(rows), int(inter), C.c_void_p(stream)), "rq_nb_swiglu_f16")
+
+
+def nb_mean_pool(h, lengths, out, batch: int, seq: int, width: int, stream: int = 0) -> None:
+    _check(load_library().rq_nb_mean_pool_f16(_ptr(h), _ptr(lengths), _ptr(out), int(batch), int(seq), int(width), C.c_void_p(stream)),
+           "rq_nb_mean_pool_f16")
 
 
 def merge_keys_device(d_keys_in, n_per_query: int, B: int, k: int, d_scores, d_rows, d_keys_out=None, stream: int = 0) -> None:

@@ -309,8 +309,12 @@ extern "C" double rq_get_option(const rq_index* idx, const char* name) {
     if (!idx->shards.empty()) {   // the statistics are shard maxima, everything else is the same on every child
         double v = rq_get_option(idx->shards[0], name);
         const std::string o(name);
-        if (o.rfind("max_", 0) == 0 || o.rfind("eps_", 0) == 0)
+        if (o.rfind("max_", 0) == 0 || o.rfind("eps_", 0) == 0 || o == "scan8_row_err" || o == "scan8_suspended")
             for (rq_index* c : idx->shards) v = std::max(v, rq_get_option(c, name));
+        if (o == "scan8_used" || o == "hints_used") {   // counters: summed
+            v = 0;
+            for (rq_index* c : idx->shards) v += rq_get_option(c, name);
+        }
         return v;
     }
     const std::string s(name);
@@ -755,7 +759,6 @@ extern "C" int rq_search_device(rq_index* idx, const float* d_queries, int B, in
     if (int r = check_search_args(idx, d_queries, B, k, metric, d_scores, d_rows)) return r;
     if (!d_status) return set_err(RQ_EINVAL, "d_status is required");
     if (!idx->shards.empty()) return set_err(RQ_EUNSUPPORTED, "device-pointer searches on a multi-device index: use rq_search (host buffers), or one index per device");
-    if (!idx->shards.empty()) return set_err(RQ_EUNSUPPORTED, "device-pointer searches on a multi-device index: use rq_search (host buffers), or one index per device");
     RQ_ON_DEVICE(idx);
     idx->t.searches++;
     idx->t.queries += B;
@@ -788,7 +791,6 @@ extern "C" int rq_search_fixup_device(rq_index* idx, const float* d_queries, int
                                       int64_t* d_rows, uint64_t* d_keys, int* d_status, void* stream) {
     if (int r = check_search_args(idx, d_queries, B, k, metric, d_scores, d_rows)) return r;
     if (!d_status) return set_err(RQ_EINVAL, "d_status is required");
-    if (!idx->shards.empty()) return set_err(RQ_EUNSUPPORTED, "device-pointer searches on a multi-device index: use rq_search (host buffers), or one index per device");
     if (!idx->shards.empty()) return set_err(RQ_EUNSUPPORTED, "device-pointer searches on a multi-device index: use rq_search (host buffers), or one index per device");
     RQ_ON_DEVICE(idx);
     hipStream_t s = (hipStream_t)stream;

@@ -1,0 +1,331 @@
+// rq_encoder.hip -- the memory-bound pieces of the NomicBert (nomic-embed-text) forward pass, fused for gfx950.
+//
+// SURVEY 8(a1/a2, f1): the reference obtains embeddings from Ollama (rag_uq/streaming_index.py:267-288); here the encoder runs
+// in-process on PyTorch-ROCm (embedders.NomicBertEmbedder).  rocprofv3 of the stock `transformers` forward at configs[3]'s
+// shape (256 queries x 68 tokens, 12 layers, fp16): 10.3 ms, of which the seven GEMMs per layer are 4.1 ms and everything
+// else -- rotary (cat / neg / mul / add), SDPA on 68-token sequences, SiLU, gate * up, residual adds, LayerNorm -- is 6 ms
+// of small memory-bound kernels.  The GEMMs stay with hipBLASLt (plain library GEMMs); the rest is four kernels here:
+//
+//   rq_nb_attention_f16      rotary + softmax(QK^T / 8 + prefix mask) V for sequences of <= 256 tokens, on the matrix cores
+//   rq_nb_add_layernorm_f16  LayerNorm(x + residual) * gamma + beta (post-LN block of NomicBertLayer)
+//   rq_nb_swiglu_f16         silu(gate) * up on the fused [gate | up] GEMM output
+//   rq_nb_mean_pool_f16      masked mean over the valid tokens of a sequence (fp32 out)
+//
+// Architecture facts used (transformers/models/nomic_bert/modeling_nomic_bert.py of the installed package): 12 heads x 64,
+// rotate-half rotary over the whole head dimension with theta from the config, no biases in the projections, post-LN,
+// SwiGLU MLP, right-padded batches (valid tokens first).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rq_device.h"
+#include "rq_index.h"   // set_err, HIPCHK
+
+#define NB_HEAD_DIM 64
+#define NB_MAX_SEQ 256      // keys one attention workgroup stages in LDS
+#define NB_QBLOCK 64        // queries per attention workgroup (16 per wave)
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Attention.  Grid (heads, batch), 256 threads: a workgroup stages the keys and values of one (sequence, head) once and walks
+// over the queries in blocks of 64 (16 per wave).  qkv: [batch * L][3 * H] fp16 with H = heads * 64 (q | k | v),
+// ctx: [batch * L][H] fp16.  len[b] = valid tokens of sequence b (the first len[b] positions); rows >= len[b] of ctx are
+// written as zeros.
+//
+// Everything is computed transposed so that no operand ever needs a cross-lane transpose:
+//   S^T = K Q^T      A = K rows (lane: key r16, dims 8 kg ..), B = Q rows (lane: query r16, dims 8 kg ..)
+//                    D[key 4 kg + i][query r16]: a lane holds 4 consecutive keys of ONE query -> the softmax statistics of a
+//                    query are lane-local sums plus two xor-shuffles (16, 32)
+//   O^T = V^T P^T    B = P^T: the lane's own D registers of two key tiles (keys 4 kg + i of tile t0, then of tile t1) -- the
+//                    k index of an MFMA is only a label, so A = V^T is read with the SAME key order: Vt[dim][key] in LDS,
+//                    two 8-byte reads per fragment
+//                    D[dim 4 kg + i][query r16]: 4 consecutive dims of one query -> one 8-byte store
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS of one workgroup, carved at run time for the batch's padded sequence length nkmax = round32(L):
+//   k  [nkmax][72] fp16   rotated keys, row-major (rows 144 B apart: conflict-free 16-byte reads)
+//   vt [64][nkmax + 8]    values transposed
+//   q  [64][72]           rotated queries of this block
+// 36 KB at L = 68 (4 workgroups per CU), 80 KB at L = 256.
+#define NB_KSTRIDE (NB_HEAD_DIM + 8)
+static inline size_t nb_attn_lds_bytes(int nkmax) { return ((size_t)nkmax * NB_KSTRIDE + (size_t)NB_HEAD_DIM * (nkmax + 8) + (size_t)NB_QBLOCK * NB_KSTRIDE) * 2; }
+
+// rope[pos][0..31] = cos(pos * theta^(-d / 32)), rope[pos][32..63] = sin(...)  (fp32; the reference module rounds them to fp16)
+__global__ void rq_nb_rope_table_kernel(float* rope, int seq, float theta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= seq * 32) return;
+    const int pos = i >> 5, d = i & 31;
+    const float ang = (float)pos * powf(theta, -(float)d * (1.f / 32.f));
+    rope[pos * 64 + d] = cosf(ang);
+    rope[pos * 64 + 32 + d] = sinf(ang);
+}
+
+// rotate the pair of 8-element groups (dims 8 j .., 32 + 8 j ..) of one row: x'[d] = x[d] c - x[d + 32] s, x'[d + 32] = x[d + 32] c + x[d] s
+__device__ __forceinline__ void nb_rotate8(const rq_half8 lo, const rq_half8 hi, const float* __restrict__ cs, rq_half8& olo, rq_half8& ohi) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float c = cs[e], sn = cs[32 + e], a = (float)lo[e], b = (float)hi[e];
+        olo[e] = (_Float16)(a * c - b * sn);
+        ohi[e] = (_Float16)(b * c + a * sn);
+    }
+}
+
+__global__ __launch_bounds__(256) void rq_nb_attention_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ len, const float* __restrict__ rope,
+                                                              _Float16* __restrict__ ctx, int L, int H, int nkmax, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char nb_smem[];
+    _Float16* const Sk = reinterpret_cast<_Float16*>(nb_smem);
+    const int vstride = nkmax + 8;
+    _Float16* const Svt = Sk + (size_t)nkmax * NB_KSTRIDE;
+    _Float16* const Sq = Svt + (size_t)NB_HEAD_DIM * vstride;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int head = blockIdx.x, b = blockIdx.y;
+    const int n = len[b] < L ? len[b] : L;                 // valid tokens (keys) of this sequence
+    const size_t row0 = (size_t)b * L;
+    const int ld = 3 * H;
+    const rq_half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    // rows of padding: zero (the residual + LayerNorm that follows reads them)
+    for (int i = n * 8 + tid; i < L * 8; i += 256) *(rq_half8*)(ctx + (row0 + (i >> 3)) * H + head * NB_HEAD_DIM + (i & 7) * 8) = zero8;
+    if (n == 0) return;
+    const int nk = (n + 31) & ~31;                          // keys padded to whole 32-key steps (<= nkmax)
+    // ---- stage K (rotated) and V^T once: 16-byte global loads, rows beyond n are zero
+    for (int i = tid; i < nk * 4; i += 256) {
+        const int r = i >> 2, j = i & 3;
+        rq_half8 olo = zero8, ohi = zero8;
+        if (r < n) {
+            const _Float16* p = qkv + (row0 + r) * ld + H + head * NB_HEAD_DIM + 8 * j;
+            nb_rotate8(*(const rq_half8*)p, *(const rq_half8*)(p + 32), rope + r * 64 + 8 * j, olo, ohi);
+        }
+        *(rq_half8*)(Sk + r * NB_KSTRIDE + 8 * j) = olo;
+        *(rq_half8*)(Sk + r * NB_KSTRIDE + 32 + 8 * j) = ohi;
+    }
+    for (int i = tid; i < nk * 8; i += 256) {
+        const int r = i >> 3, j = i & 7;
+        rq_half8 v = zero8;
+        if (r < n) v = *(const rq_half8*)(qkv + (row0 + r) * ld + 2 * H + head * NB_HEAD_DIM + 8 * j);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Svt[(8 * j + e) * vstride + r] = v[e];
+    }
+    const int r16 = lane & 15, kg = lane >> 4;
+    // ---- blocks of 64 queries (16 per wave); K / V^T stay, the Q block is restaged
+    for (int q0 = 0; q0 < n; q0 += NB_QBLOCK) {
+        if (q0) __syncthreads();                            // every wave is done with the previous Q block
+        for (int i = tid; i < NB_QBLOCK * 4; i += 256) {
+            const int r = i >> 2, j = i & 3, pos = q0 + r;
+            rq_half8 olo = zero8, ohi = zero8;
+            if (pos < n) {
+                const _Float16* p = qkv + (row0 + pos) * ld + head * NB_HEAD_DIM + 8 * j;
+                nb_rotate8(*(const rq_half8*)p, *(const rq_half8*)(p + 32), rope + pos * 64 + 8 * j, olo, ohi);
+            }
+            *(rq_half8*)(Sq + r * NB_KSTRIDE + 8 * j) = olo;
+            *(rq_half8*)(Sq + r * NB_KSTRIDE + 32 + 8 * j) = ohi;
+        }
+        __syncthreads();
+        if (q0 + 16 * wave >= n) continue;                  // (uniform per wave) none of this wave's 16 queries is a token
+        // B operand of S^T = K Q^T: this wave's 16 queries, dims 8 kg .. (k-steps 0 and 1)
+        const rq_half8 qf0 = *(const rq_half8*)(Sq + (16 * wave + r16) * NB_KSTRIDE + 8 * kg);
+        const rq_half8 qf1 = *(const rq_half8*)(Sq + (16 * wave + r16) * NB_KSTRIDE + 32 + 8 * kg);
+        float m = -__builtin_huge_valf(), l = 0.f;          // running max / sum of this lane's query (identical on its 4 lanes)
+        rq_float4 o[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        for (int k0 = 0; k0 < nk; k0 += 32) {
+            rq_float4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+            {
+                const _Float16* kr = Sk + (k0 + r16) * NB_KSTRIDE + 8 * kg;
+                const rq_half8 a00 = *(const rq_half8*)kr, a01 = *(const rq_half8*)(kr + 32);
+                const rq_half8 a10 = *(const rq_half8*)(kr + 16 * NB_KSTRIDE), a11 = *(const rq_half8*)(kr + 16 * NB_KSTRIDE + 32);
+                s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a00, qf0, s0, 0, 0, 0);
+                s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a01, qf1, s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a10, qf0, s1, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a11, qf1, s1, 0, 0, 0);
+            }
+            // scale, prefix mask, online softmax over this lane's 8 keys + the 3 other lanes of the query
+            float sv[8], mx = -__builtin_huge_valf();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sv[i] = (k0 + 4 * kg + i < n) ? s0[i] * scale : -__builtin_huge_valf();
+                sv[4 + i] = (k0 + 16 + 4 * kg + i < n) ? s1[i] * scale : -__builtin_huge_valf();
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) mx = fmaxf(mx, sv[i]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(m, mx);                  // finite: key 0 is always valid (n >= 1)
+            const float alpha = __expf(m - mn);
+            float ps = 0.f;
+            rq_half8 pf;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float p = __expf(sv[i] - mn);         // exp(-inf) = 0 for masked keys
+                ps += p;
+                pf[i] = (_Float16)p;
+            }
+            ps += __shfl_xor(ps, 16, 64);
+            ps += __shfl_xor(ps, 32, 64);
+            l = l * alpha + ps;
+            m = mn;
+            // O^T += V^T P^T: A fragment of dim tile t = Vt[16 t + r16][keys 4 kg .. of tile k0, then of tile k0 + 16]
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const rq_half4 v0 = *(const rq_half4*)(Svt + (16 * t + r16) * vstride + k0 + 4 * kg);
+                const rq_half4 v1 = *(const rq_half4*)(Svt + (16 * t + r16) * vstride + k0 + 16 + 4 * kg);
+                const rq_half8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[t][i] *= alpha;
+                o[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[t], 0, 0, 0);
+            }
+        }
+        // ---- O[query][dim 16 t + 4 kg + i] = o[t][i] / l
+        const int pos = q0 + 16 * wave + r16;
+        if (pos < n) {
+            const float inv = 1.f / l;
+            _Float16* dst = ctx + (row0 + pos) * H + head * NB_HEAD_DIM + 4 * kg;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                rq_half4 h;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) h[i] = (_Float16)(o[t][i] * inv);
+                *(rq_half4*)(dst + 16 * t) = h;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// out = LayerNorm(x + res) * gamma + beta over rows of `width` <= 1536 elements (multiple of 8); one wave per row, fp32
+// statistics (two-pass over registers).  res may be null; out may alias x or res.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rq_nb_add_layernorm_kernel(const _Float16* x, const _Float16* res, const _Float16* __restrict__ gamma,
+                                                                  const _Float16* __restrict__ beta, _Float16* out, int64_t rows, int width, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[24];
+    float sum = 0.f;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const int c = (p * 64 + lane) * 8;
+        if (c < width) {
+            const rq_half8 a = *(const rq_half8*)(x + row * width + c);
+            rq_half8 r = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (res) r = *(const rq_half8*)(res + row * width + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[p * 8 + e] = (float)a[e] + (float)r[e]; sum += v[p * 8 + e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[p * 8 + e] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    const float mean = sum / (float)width;
+    float var = 0.f;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const int c = (p * 64 + lane) * 8;
+        if (c < width)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[p * 8 + e] - mean; var += d * d; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) var += __shfl_xor(var, off, 64);
+    const float rstd = rsqrtf(var / (float)width + eps);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const int c = (p * 64 + lane) * 8;
+        if (c < width) {
+            const rq_half8 g = *(const rq_half8*)(gamma + c), bt = *(const rq_half8*)(beta + c);
+            rq_half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (_Float16)((v[p * 8 + e] - mean) * rstd * (float)g[e] + (float)bt[e]);
+            *(rq_half8*)(out + row * width + c) = o;
+        }
+    }
+}
+
+// out[t][j] = silu(gu[t][j]) * gu[t][inter + j];  gu: [rows][2 * inter], out: [rows][inter]; inter % 8 == 0
+__global__ __launch_bounds__(256) void rq_nb_swiglu_kernel(const _Float16* __restrict__ gu, _Float16* __restrict__ out, int64_t rows, int inter) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i >= rows * inter) return;
+    const int64_t t = i / inter;
+    const int j = (int)(i - t * inter);
+    const rq_half8 g = *(const rq_half8*)(gu + t * 2 * inter + j), u = *(const rq_half8*)(gu + t * 2 * inter + inter + j);
+    rq_half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = (float)g[e];
+        o[e] = (_Float16)(x / (1.f + __expf(-x)) * (float)u[e]);
+    }
+    *(rq_half8*)(out + i) = o;
+}
+
+// out[b][d] = sum over the first len[b] tokens of h[b][t][d] / max(len[b], 1), fp32.  Grid (batch), 256 threads; width <= 2048.
+__global__ __launch_bounds__(256) void rq_nb_mean_pool_kernel(const _Float16* __restrict__ h, const int* __restrict__ len, float* __restrict__ out, int L, int width) {
+    const int b = blockIdx.x;
+    const int n = len[b] < L ? len[b] : L;
+    for (int c = threadIdx.x * 8; c < width; c += 256 * 8) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < n; ++t) {
+            const rq_half8 v = *(const rq_half8*)(h + ((size_t)b * L + t) * width + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+        }
+        const float inv = 1.f / (float)(n > 0 ? n : 1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out[(size_t)b * width + c + e] = acc[e] * inv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// C ABI (include/rq.h).  Device pointers, the caller's stream; shapes are checked on the host before any launch.
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int rq_nb_rope_table_f32(float* d_rope, int seq, float rope_theta, void* stream) {
+    if (!d_rope) return set_err(RQ_EINVAL, "null argument");
+    if (seq < 1 || seq > 65536 || !(rope_theta > 1.f)) return set_err(RQ_EINVAL, "seq %d / rope_theta %g", seq, (double)rope_theta);
+    hipLaunchKernelGGL(rq_nb_rope_table_kernel, dim3((unsigned)((seq * 32 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_rope, seq, rope_theta);
+    HIPCHK(hipGetLastError());
+    return RQ_OK;
+}
+
+extern "C" int rq_nb_attention_f16(const void* d_qkv, const int* d_len, const float* d_rope, void* d_ctx, int batch, int seq, int heads, void* stream) {
+    if (!d_qkv || !d_len || !d_rope || !d_ctx) return set_err(RQ_EINVAL, "null argument");
+    if (batch < 1 || batch > 65535 || heads < 1 || heads > 65535) return set_err(RQ_EINVAL, "batch %d / heads %d outside 1..65535", batch, heads);
+    if (seq < 1 || seq > NB_MAX_SEQ) return set_err(RQ_EUNSUPPORTED, "sequence length %d outside 1..%d: use the framework's attention for longer inputs", seq, NB_MAX_SEQ);
+    const int nkmax = (seq + 31) & ~31;
+    const size_t lds = nb_attn_lds_bytes(nkmax);
+    const dim3 grid((unsigned)heads, (unsigned)batch);
+    static unsigned long long attr_done = 0;   // one bit per device
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    if (!((attr_done >> (dev & 63)) & 1ull)) {
+        HIPCHK(hipFuncSetAttribute((const void*)rq_nb_attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb_attn_lds_bytes(NB_MAX_SEQ)));
+        attr_done |= 1ull << (dev & 63);
+    }
+    hipLaunchKernelGGL(rq_nb_attention_kernel, grid, dim3(256), lds, (hipStream_t)stream, (const _Float16*)d_qkv, d_len, d_rope, (_Float16*)d_ctx, seq,
+                       heads * NB_HEAD_DIM, nkmax, 0.125f);
+    HIPCHK(hipGetLastError());
+    return RQ_OK;
+}
+
+extern "C" int rq_nb_add_layernorm_f16(const void* d_x, const void* d_res, const void* d_gamma, const void* d_beta, void* d_out, int64_t rows, int width,
+                                       float eps, void* stream) {
+    if (!d_x || !d_gamma || !d_beta || !d_out) return set_err(RQ_EINVAL, "null argument");
+    if (rows < 1 || width < 8 || width > 1536 || width % 8) return set_err(RQ_EINVAL, "rows %lld / width %d (8..1536, multiple of 8)", (long long)rows, width);
+    hipLaunchKernelGGL(rq_nb_add_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)d_x,
+                       (const _Float16*)d_res, (const _Float16*)d_gamma, (const _Float16*)d_beta, (_Float16*)d_out, rows, width, eps);
+    HIPCHK(hipGetLastError());
+    return RQ_OK;
+}
+
+extern "C" int rq_nb_swiglu_f16(const void* d_gate_up, void* d_out, int64_t rows, int inter, void* stream) {
+    if (!d_gate_up || !d_out) return set_err(RQ_EINVAL, "null argument");
+    if (rows < 1 || inter < 8 || inter % 8) return set_err(RQ_EINVAL, "rows %lld / intermediate size %d (multiple of 8)", (long long)rows, inter);
+    const int64_t vec = rows * inter / 8;
+    hipLaunchKernelGGL(rq_nb_swiglu_kernel, dim3((unsigned)((vec + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)d_gate_up, (_Float16*)d_out,
+                       rows, inter);
+    HIPCHK(hipGetLastError());
+    return RQ_OK;
+}
+
+extern "C" int rq_nb_mean_pool_f16(const void* d_h, const int* d_len, float* d_out, int batch, int seq, int width, void* stream) {
+    if (!d_h || !d_len || !d_out) return set_err(RQ_EINVAL, "null argument");
+    if (batch < 1 || seq < 1 || width < 8 || width > 2048 || width % 8) return set_err(RQ_EINVAL, "batch %d / seq %d / width %d", batch, seq, width);
+    hipLaunchKernelGGL(rq_nb_mean_pool_kernel, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, (const _Float16*)d_h, d_len, d_out, seq, width);
+    HIPCHK(hipGetLastError());
+    return RQ_OK;
+}

@@ -76,6 +76,88 @@ class CallableEmbedder:
         return v
 
 
+class FusedNomicBertForward:
+    """The NomicBert encoder stack with the memory-bound work fused into four gfx950 kernels (csrc/rq_encoder.hip, include/rq.h
+    "encoder pieces"); the GEMMs stay with the framework (hipBLASLt through `torch.nn.functional.linear`).
+
+    Built from a `transformers` NomicBertModel (its weights are re-used, q/k/v and gate/up concatenated so that a layer is four
+    GEMMs instead of seven).  Per layer: qkv GEMM -> rq_nb_attention_f16 (rotary + softmax(QK^T/8) V on the matrix cores,
+    prefix mask from the sequence lengths) -> o GEMM -> rq_nb_add_layernorm_f16 -> gate|up GEMM -> rq_nb_swiglu_f16 -> down GEMM
+    -> rq_nb_add_layernorm_f16; then rq_nb_mean_pool_f16.  Preconditions (checked by `usable`): fp16 on a GPU, head_dim 64,
+    hidden size <= 1536, right-padded batches of at most 256 tokens.  Architecture as in
+    transformers/models/nomic_bert/modeling_nomic_bert.py of the installed package (post-LN, rotate-half rotary, SwiGLU, no
+    projection biases).  rocprofv3 at configs[3]'s shape (256 x 68 tokens, 12 layers): stock forward 10.3 ms, see DESIGN.md 6.
+    """
+
+    MAX_SEQ = 256
+
+    def __init__(self, model):
+        import torch
+        from . import _native
+        self.torch, self.nat = torch, _native
+        cfg = model.config
+        self.heads = int(cfg.num_attention_heads)
+        self.hidden = int(cfg.hidden_size)
+        self.inter = int(cfg.intermediate_size)
+        self.eps = float(cfg.layer_norm_eps)
+        rope = getattr(cfg, "rope_parameters", None) or {}
+        self.theta = float(rope.get("rope_theta", getattr(cfg, "rope_theta", 10000.0)))
+        self.ok = (getattr(cfg, "head_dim", self.hidden // self.heads) == 64 and self.heads * 64 == self.hidden and self.hidden <= 1536
+                   and self.hidden % 8 == 0 and self.inter % 8 == 0 and rope.get("rope_type", "default") == "default"
+                   and cfg.hidden_act in ("silu", "swish"))
+        self.emb = model.embeddings
+        self.layers = []
+        self._rope = None          # rotary table [MAX_SEQ][64] fp32, built on first use
+        if not self.ok:
+            return
+        for lyr in model.encoder.layers if hasattr(model, "encoder") else model.layers:
+            a, m = lyr.self_attn, lyr.mlp
+            if any(x.bias is not None for x in (a.q_proj, a.k_proj, a.v_proj, a.o_proj, m.gate_proj, m.up_proj, m.down_proj)):
+                self.ok = False
+                return
+            self.layers.append(dict(
+                wqkv=torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0).contiguous(),
+                wo=a.o_proj.weight.contiguous(),
+                wgu=torch.cat([m.gate_proj.weight, m.up_proj.weight], 0).contiguous(),
+                wd=m.down_proj.weight.contiguous(),
+                g1=lyr.post_attention_layernorm.weight.contiguous(), b1=lyr.post_attention_layernorm.bias.contiguous(),
+                g2=lyr.post_mlp_layernorm.weight.contiguous(), b2=lyr.post_mlp_layernorm.bias.contiguous()))
+
+    def usable(self, ids, mask) -> bool:
+        torch = self.torch
+        if not (self.ok and ids.is_cuda and ids.shape[1] <= self.MAX_SEQ and self.layers and self.layers[0]["wqkv"].dtype == torch.float16):
+            return False
+        lengths = mask.sum(1)
+        return bool((mask == (torch.arange(mask.shape[1], device=mask.device)[None, :] < lengths[:, None])).all())   # valid tokens first
+
+    def __call__(self, ids, mask):
+        """[B][L] token ids + right-padded attention mask -> [B][hidden] fp32 mean-pooled embeddings (device tensor)."""
+        torch, nat = self.torch, self.nat
+        F = torch.nn.functional
+        B, L = ids.shape
+        T, H = B * L, self.hidden
+        st = torch.cuda.current_stream(ids.device).cuda_stream
+        lengths = mask.sum(1).to(torch.int32).contiguous()
+        h = self.emb(input_ids=ids, position_ids=torch.arange(L, device=ids.device)[None, :]).reshape(T, H).contiguous()
+        if self._rope is None or self._rope.device != ids.device:
+            self._rope = torch.empty((self.MAX_SEQ, 64), device=ids.device, dtype=torch.float32)
+            nat.nb_rope_table(self._rope, self.MAX_SEQ, self.theta, st)
+        ctx = torch.empty((T, H), device=ids.device, dtype=torch.float16)
+        act = torch.empty((T, self.inter), device=ids.device, dtype=torch.float16)
+        for w in self.layers:
+            qkv = F.linear(h, w["wqkv"])
+            nat.nb_attention(qkv, lengths, self._rope, ctx, B, L, self.heads, st)
+            o = F.linear(ctx, w["wo"])
+            nat.nb_add_layernorm(o, h, w["g1"], w["b1"], h, T, H, self.eps, st)
+            gu = F.linear(h, w["wgu"])
+            nat.nb_swiglu(gu, act, T, self.inter, st)
+            d = F.linear(act, w["wd"])
+            nat.nb_add_layernorm(d, h, w["g2"], w["b2"], h, T, H, self.eps, st)
+        out = torch.empty((B, H), device=ids.device, dtype=torch.float32)
+        nat.nb_mean_pool(h, lengths, out, B, L, H, st)
+        return out
+
+
 class NomicBertEmbedder:
     """nomic-embed-text forward pass on PyTorch-ROCm (BASELINE.json configs[3]).
 
@@ -90,7 +172,8 @@ class NomicBertEmbedder:
     dim = 768
 
     def __init__(self, model_path: Optional[str] = None, device: str = "cuda:0", dtype: str = "float16",
-                 max_length: int = 512, batch_size: int = 256, random_init: bool = False, num_layers: Optional[int] = None):
+                 max_length: int = 512, batch_size: int = 256, random_init: bool = False, num_layers: Optional[int] = None,
+                 fused: bool = True):
         import torch
 
         self.torch = torch
@@ -120,6 +203,13 @@ class NomicBertEmbedder:
             self.vocab = int(AutoConfig.from_pretrained(model_path, local_files_only=True).vocab_size)
         self.model = self.model.to(self.device, self.dtype).eval()
         self.dim = int(self.model.config.hidden_size)
+        # fp16 on a GPU: the fused gfx950 forward (batches it cannot take -- more than 256 tokens, left padding -- go through
+        # the stock module, same weights)
+        self.fused = None
+        if fused and self.device.type == "cuda" and self.dtype == torch.float16:
+            with torch.inference_mode():
+                f = FusedNomicBertForward(self.model)
+            self.fused = f if f.ok else None
 
     def _tokenize(self, texts: Sequence[str]):
         torch = self.torch
@@ -127,14 +217,17 @@ class NomicBertEmbedder:
             enc = self.tokenizer(list(texts), padding=True, truncation=True, max_length=self.max_length, return_tensors="pt")
             return enc["input_ids"].to(self.device), enc["attention_mask"].to(self.device)
         # stand-in: utf-8 bytes shifted into the vocabulary (random-init smoke path only)
-        rows = [[(b % (self.vocab - 10)) + 5 for b in t.encode()[: self.max_length]] or [5] for t in texts]
-        L = max(len(r) for r in rows)
-        ids = torch.zeros((len(rows), L), dtype=torch.long)
-        mask = torch.zeros((len(rows), L), dtype=torch.long)
-        for i, r in enumerate(rows):
-            ids[i, : len(r)] = torch.tensor(r)
-            mask[i, : len(r)] = 1
-        return ids.to(self.device), mask.to(self.device)
+        raw = [np.frombuffer(t.encode()[: self.max_length], dtype=np.uint8) for t in texts]
+        L = max(max((len(r) for r in raw), default=1), 1)
+        ids = np.zeros((len(raw), L), dtype=np.int64)
+        mask = np.zeros((len(raw), L), dtype=np.int64)
+        for i, r in enumerate(raw):
+            if len(r) == 0:
+                ids[i, 0] = 5; mask[i, 0] = 1                      # an empty text is one token
+            else:
+                ids[i, : len(r)] = r.astype(np.int64) % (self.vocab - 10) + 5
+                mask[i, : len(r)] = 1
+        return torch.from_numpy(ids).to(self.device), torch.from_numpy(mask).to(self.device)
 
     def embed(self, texts: Sequence[str]) -> np.ndarray:
         torch = self.torch
@@ -142,6 +235,9 @@ class NomicBertEmbedder:
         with torch.inference_mode():
             for lo in range(0, len(texts), self.batch_size):
                 ids, mask = self._tokenize(texts[lo: lo + self.batch_size])
+                if self.fused is not None and self.fused.usable(ids, mask):
+                    outs.append(self.fused(ids, mask).cpu().numpy())
+                    continue
                 h = self.model(input_ids=ids, attention_mask=mask).last_hidden_state.float()
                 m = mask.unsqueeze(-1).float()
                 outs.append(((h * m).sum(1) / m.sum(1).clamp_min(1.0)).cpu().numpy())

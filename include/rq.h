@@ -177,6 +177,26 @@ int rq_debug_stamps(rq_index* idx, int enable, unsigned long long* out, int max_
 const char* rq_last_error(void);
 const char* rq_version(void);
 
+/* ---- encoder pieces (the embedding the reference asks Ollama for, rag_uq/streaming_index.py:267-288) ----
+ * The memory-bound parts of the NomicBert (nomic-embed-text) forward pass as fused gfx950 kernels; the GEMMs between them stay
+ * with the framework's library (hipBLASLt).  All pointers are device pointers, fp16 unless noted; `stream` is a hipStream_t.
+ * Used by embedders.NomicBertEmbedder (efficient-rag-..._amd/embedders.py), csrc/rq_encoder.hip. */
+/* d_rope[pos][0..31] = cos(pos * rope_theta^(-d / 32)), d_rope[pos][32..63] = the sines (fp32 [seq][64]): the rotary table. */
+int rq_nb_rope_table_f32(float* d_rope, int seq, float rope_theta, void* stream);
+/* ctx[b][t][:] = softmax(rot(q) rot(k)^T / 8 + prefix mask) v per head.  d_qkv [batch * seq][3 * heads * 64] (q | k | v of the
+ * fused projection), d_len[batch] = valid tokens of each sequence (the first d_len[b] positions; padded rows come out zero),
+ * rotary = rotate-half over the 64 dims with d_rope (at least seq rows).  seq <= 256 (RQ_EUNSUPPORTED beyond: use the
+ * framework's attention). */
+int rq_nb_attention_f16(const void* d_qkv, const int* d_len, const float* d_rope, void* d_ctx, int batch, int seq, int heads, void* stream);
+/* out = LayerNorm(x + res) * gamma + beta over rows of `width` (8..1536, multiple of 8) elements, fp32 statistics; res may be
+ * NULL; out may alias x or res. */
+int rq_nb_add_layernorm_f16(const void* d_x, const void* d_res, const void* d_gamma, const void* d_beta, void* d_out, int64_t rows, int width,
+                            float eps, void* stream);
+/* out[t][j] = silu(gate_up[t][j]) * gate_up[t][inter + j]: d_gate_up [rows][2 * inter] (gate | up), d_out [rows][inter]. */
+int rq_nb_swiglu_f16(const void* d_gate_up, void* d_out, int64_t rows, int inter, void* stream);
+/* d_out[b][:] (fp32) = mean of d_h[b][t][:] over the first d_len[b] tokens (0 for an empty sequence). */
+int rq_nb_mean_pool_f16(const void* d_h, const int* d_len, float* d_out, int batch, int seq, int width, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

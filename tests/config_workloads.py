@@ -139,7 +139,7 @@ def run_config3(n: int = 1_000_000, n_queries: int = 256, k: int = 10, num_layer
     gs, gr = orc.dense_topk(qv, x16, k)
     got_r = np.array([[int(d[1:]) for d, _, _ in r] for r in res])
     got_s = np.array([[s for _, s, _ in r] for r in res], dtype=np.float32)
-    out = {"workload": f"{n_queries} raw text queries -> NomicBert ({num_layers} layers, 768 hidden, fp16, PyTorch-ROCm eager) -> exact top-{k} over {n}x768 fp16",
+    out = {"workload": f"{n_queries} raw text queries -> NomicBert ({num_layers} layers, 768 hidden, fp16; hipBLASLt GEMMs + fused gfx950 kernels, csrc/rq_encoder.hip) -> exact top-{k} over {n}x768 fp16",
            "data": "synthetic stand-in (random-init NomicBert + byte-level tokenizer: no nomic-embed-text weights offline; Gaussian passage vectors)",
            "encode_ms": t_enc / reps * 1e3, "search_ms": t_search / reps * 1e3, "end_to_end_ms": t_e2e / reps * 1e3,
            "text_queries_per_s": n_queries / (t_e2e / reps),

@@ -1404,3 +1404,85 @@ def test_int8_scan_bin_maxima_within_its_measured_bound():
         er = np.linalg.norm(x - sr * np.rint(x / np.where(sr > 0, sr, 1)), axis=1) / np.linalg.norm(x, axis=1)
     assert e_rows == pytest.approx(float(np.nanmax(er)), rel=1e-3)
     idx.close()
+
+
+# ---- encoder pieces (csrc/rq_encoder.hip): each kernel against a plain PyTorch fp32 reference of the same op ------------
+def _rotate_half_ref(x):
+    import torch
+    return torch.cat((-x[..., 32:], x[..., :32]), dim=-1)
+
+
+def test_encoder_kernels_match_fp32_torch_references():
+    """rq_nb_attention_f16 (rotary + masked softmax attention on the matrix cores), rq_nb_add_layernorm_f16, rq_nb_swiglu_f16,
+    rq_nb_mean_pool_f16 against fp32 PyTorch on the same fp16 inputs.  Tolerances: attention 2e-3 absolute (P is rounded to
+    fp16 before the PV product, outputs are fp16), LayerNorm / SwiGLU 1 fp16 ulp of the result range, mean pool 1e-6."""
+    import torch
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    for B, L, heads in ((3, 68, 12), (2, 256, 2), (5, 17, 1), (1, 1, 12)):
+        H = heads * 64
+        qkv = (torch.randn((B * L, 3 * H), device=dev, generator=g) * 1.5).half()
+        lens = torch.tensor([L, max(L // 3, 1), 0, 1, L - 1][:B], device=dev, dtype=torch.int32).clamp(max=L)
+        ctx = torch.full((B * L, H), 7.0, device=dev, dtype=torch.float16)
+        rope = torch.empty((L, 64), device=dev)
+        nat.nb_rope_table(rope, L, 1000.0)
+        nat.nb_attention(qkv, lens, rope, ctx, B, L, heads)
+        torch.cuda.synchronize()
+        x = qkv.float().view(B, L, 3, heads, 64).permute(2, 0, 3, 1, 4)                     # [3][B][heads][L][64]
+        pos = torch.arange(L, device=dev, dtype=torch.float32)
+        inv = 1000.0 ** (-torch.arange(0, 32, device=dev, dtype=torch.float32) / 32.0)
+        ang = torch.cat([pos[:, None] * inv[None, :]] * 2, dim=-1)                          # [L][64]
+        q = x[0] * ang.cos() + _rotate_half_ref(x[0]) * ang.sin()
+        k = x[1] * ang.cos() + _rotate_half_ref(x[1]) * ang.sin()
+        s = (q @ k.transpose(-1, -2)) * 0.125
+        keymask = torch.arange(L, device=dev)[None, :] < lens[:, None]                      # [B][L]
+        s = s.masked_fill(~keymask[:, None, None, :], float("-inf"))
+        ref = torch.nan_to_num(torch.softmax(s, dim=-1)) @ x[2]                             # [B][heads][L][64]
+        ref = ref.permute(0, 2, 1, 3).reshape(B, L, H) * keymask[:, :, None]                # padded query rows: zero
+        got = ctx.float().view(B, L, H)
+        assert torch.isfinite(got).all()
+        assert float((got - ref).abs().max()) <= 2e-3 * max(1.0, float(ref.abs().max())), (B, L, heads, float((got - ref).abs().max()))
+    rows, width = 1000, 768
+    xx = torch.randn((rows, width), device=dev, generator=g).half(); rr = (torch.randn((rows, width), device=dev, generator=g) * 3).half()
+    gam = (1 + 0.1 * torch.randn((width,), device=dev, generator=g)).half(); bet = (0.1 * torch.randn((width,), device=dev, generator=g)).half()
+    out = torch.empty_like(xx)
+    nat.nb_add_layernorm(xx, rr, gam, bet, out, rows, width, 1e-12)
+    ref = torch.nn.functional.layer_norm(xx.float() + rr.float(), (width,), gam.float(), bet.float(), 1e-12)
+    assert float((out.float() - ref).abs().max()) <= 4e-3
+    nat.nb_add_layernorm(xx, None, gam, bet, xx, rows, width, 1e-12)                        # no residual, in place
+    assert torch.isfinite(xx).all()
+    gu = torch.randn((333, 2 * 3072), device=dev, generator=g).half()
+    act = torch.empty((333, 3072), device=dev, dtype=torch.float16)
+    nat.nb_swiglu(gu, act, 333, 3072)
+    ref = torch.nn.functional.silu(gu[:, :3072].float()) * gu[:, 3072:].float()
+    assert float((act.float() - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
+    hh = torch.randn((4, 50, 768), device=dev, generator=g).half()
+    ln = torch.tensor([50, 1, 0, 23], device=dev, dtype=torch.int32)
+    pooled = torch.empty((4, 768), device=dev)
+    nat.nb_mean_pool(hh, ln, pooled, 4, 50, 768)
+    mk = (torch.arange(50, device=dev)[None, :] < ln[:, None]).float()[:, :, None]
+    ref = (hh.float() * mk).sum(1) / mk.sum(1).clamp_min(1.0)
+    assert float((pooled - ref).abs().max()) <= 1e-5
+    with pytest.raises(nat.RqError):
+        nat.nb_attention(qkv, lens, rope, ctx, 1, 257, 1)                                   # longer than one workgroup stages
+
+
+def test_fused_nomic_bert_forward_matches_the_stock_module():
+    """embedders.FusedNomicBertForward (four GEMMs per layer + the fused kernels) against the stock `transformers` forward of
+    the SAME fp16 weights on the same tokens: ragged lengths 1..200, 4 layers -- per-text cosine >= 0.9999, and batches the
+    fused path declines (more than 256 tokens) come out of the stock path unchanged."""
+    import torch
+    from rag_uq_amd.embedders import NomicBertEmbedder
+    torch.manual_seed(1)
+    fused = NomicBertEmbedder(random_init=True, num_layers=4, device="cuda:0", dtype="float16", batch_size=64)
+    stock = NomicBertEmbedder(random_init=True, num_layers=4, device="cuda:0", dtype="float16", batch_size=64, fused=False)
+    stock.model.load_state_dict(fused.model.state_dict())
+    assert fused.fused is not None and stock.fused is None
+    texts = [("word%d " % (i * 37 % 101)) * (1 + i % 28) for i in range(150)] + ["", "a"]
+    a, b = fused.embed(texts), stock.embed(texts)
+    assert a.shape == b.shape == (152, 768) and np.isfinite(a).all()
+    cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+    assert cos.min() >= 0.9999, cos.min()
+    assert float(np.abs(a - b).max()) <= 0.02 * float(np.abs(b).max())
+    long_texts = ["y" * 400, "z" * 300]
+    assert np.array_equal(fused.embed(long_texts), stock.embed(long_texts))               # 400 tokens: the stock path on both sides
