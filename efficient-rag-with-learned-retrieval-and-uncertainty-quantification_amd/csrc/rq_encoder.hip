@@ -6,7 +6,7 @@
 // else -- rotary (cat / neg / mul / add), SDPA on 68-token sequences, SiLU, gate * up, residual adds, LayerNorm -- is 6 ms
 // of small memory-bound kernels.  The GEMMs stay with hipBLASLt (plain library GEMMs); the rest is four kernels here:
 //
-//   rq_nb_attention_f16      rotary + softmax(QK^T / 8 + prefix mask) V for sequences of <= 256 tokens, on the matrix cores
+//   rq_nb_attention_f16      rotary + softmax(QK^T / 8 + prefix mask) V for sequences of <= 512 tokens, on the matrix cores
 //   rq_nb_add_layernorm_f16  LayerNorm(x + residual) * gamma + beta (post-LN block of NomicBertLayer)
 //   rq_nb_swiglu_f16         silu(gate) * up on the fused [gate | up] GEMM output
 //   rq_nb_mean_pool_f16      masked mean over the valid tokens of a sequence (fp32 out)
@@ -21,7 +21,7 @@
 #include "rq_index.h"   // set_err, HIPCHK
 
 #define NB_HEAD_DIM 64
-#define NB_MAX_SEQ 256      // keys one attention workgroup stages in LDS
+#define NB_MAX_SEQ 512      // keys one attention workgroup stages in LDS (150 KB at 512: one workgroup per CU)
 #define NB_QBLOCK 64        // queries per attention workgroup (16 per wave)
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -43,7 +43,7 @@
 //   k  [nkmax][72] fp16   rotated keys, row-major (rows 144 B apart: conflict-free 16-byte reads)
 //   vt [64][nkmax + 8]    values transposed
 //   q  [64][72]           rotated queries of this block
-// 36 KB at L = 68 (4 workgroups per CU), 80 KB at L = 256.
+// 36 KB at L = 68 (4 workgroups per CU), 80 KB at L = 256, 150 KB at L = 512 (the CU's 160 KB: one workgroup).
 #define NB_KSTRIDE (NB_HEAD_DIM + 8)
 static inline size_t nb_attn_lds_bytes(int nkmax) { return ((size_t)nkmax * NB_KSTRIDE + (size_t)NB_HEAD_DIM * (nkmax + 8) + (size_t)NB_QBLOCK * NB_KSTRIDE) * 2; }
 

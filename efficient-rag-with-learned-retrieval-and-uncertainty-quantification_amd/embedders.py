@@ -84,12 +84,12 @@ class FusedNomicBertForward:
     GEMMs instead of seven).  Per layer: qkv GEMM -> rq_nb_attention_f16 (rotary + softmax(QK^T/8) V on the matrix cores,
     prefix mask from the sequence lengths) -> o GEMM -> rq_nb_add_layernorm_f16 -> gate|up GEMM -> rq_nb_swiglu_f16 -> down GEMM
     -> rq_nb_add_layernorm_f16; then rq_nb_mean_pool_f16.  Preconditions (checked by `usable`): fp16 on a GPU, head_dim 64,
-    hidden size <= 1536, right-padded batches of at most 256 tokens.  Architecture as in
+    hidden size <= 1536, right-padded batches of at most 512 tokens.  Architecture as in
     transformers/models/nomic_bert/modeling_nomic_bert.py of the installed package (post-LN, rotate-half rotary, SwiGLU, no
     projection biases).  rocprofv3 at configs[3]'s shape (256 x 68 tokens, 12 layers): stock forward 10.3 ms, see DESIGN.md 6.
     """
 
-    MAX_SEQ = 256
+    MAX_SEQ = 512
 
     def __init__(self, model):
         import torch
@@ -203,7 +203,7 @@ class NomicBertEmbedder:
             self.vocab = int(AutoConfig.from_pretrained(model_path, local_files_only=True).vocab_size)
         self.model = self.model.to(self.device, self.dtype).eval()
         self.dim = int(self.model.config.hidden_size)
-        # fp16 on a GPU: the fused gfx950 forward (batches it cannot take -- more than 256 tokens, left padding -- go through
+        # fp16 on a GPU: the fused gfx950 forward (batches it cannot take -- more than 512 tokens, left padding -- go through
         # the stock module, same weights)
         self.fused = None
         if fused and self.device.type == "cuda" and self.dtype == torch.float16:
@@ -231,17 +231,24 @@ class NomicBertEmbedder:
 
     def embed(self, texts: Sequence[str]) -> np.ndarray:
         torch = self.torch
-        outs = []
+        texts = list(texts)
+        if not texts:
+            return np.zeros((0, self.dim), np.float32)
+        # batches of similar length: a batch is padded to its longest text, so ragged inputs (passages) are sorted by length
+        # first and the rows are put back in the caller's order afterwards
+        order = sorted(range(len(texts)), key=lambda i: len(texts[i])) if len(texts) > self.batch_size else list(range(len(texts)))
+        out = np.empty((len(texts), self.dim), np.float32)
         with torch.inference_mode():
-            for lo in range(0, len(texts), self.batch_size):
-                ids, mask = self._tokenize(texts[lo: lo + self.batch_size])
+            for lo in range(0, len(order), self.batch_size):
+                sel = order[lo: lo + self.batch_size]
+                ids, mask = self._tokenize([texts[i] for i in sel])
                 if self.fused is not None and self.fused.usable(ids, mask):
-                    outs.append(self.fused(ids, mask).cpu().numpy())
+                    out[sel] = self.fused(ids, mask).cpu().numpy()
                     continue
                 h = self.model(input_ids=ids, attention_mask=mask).last_hidden_state.float()
                 m = mask.unsqueeze(-1).float()
-                outs.append(((h * m).sum(1) / m.sum(1).clamp_min(1.0)).cpu().numpy())
-        return np.concatenate(outs, axis=0).astype(np.float32) if outs else np.zeros((0, self.dim), np.float32)
+                out[sel] = ((h * m).sum(1) / m.sum(1).clamp_min(1.0)).cpu().numpy()
+        return out
 
 
 def default_embedder(embedding_model: str = "nomic-embed-text"):

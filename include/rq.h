@@ -185,7 +185,7 @@ const char* rq_version(void);
 int rq_nb_rope_table_f32(float* d_rope, int seq, float rope_theta, void* stream);
 /* ctx[b][t][:] = softmax(rot(q) rot(k)^T / 8 + prefix mask) v per head.  d_qkv [batch * seq][3 * heads * 64] (q | k | v of the
  * fused projection), d_len[batch] = valid tokens of each sequence (the first d_len[b] positions; padded rows come out zero),
- * rotary = rotate-half over the 64 dims with d_rope (at least seq rows).  seq <= 256 (RQ_EUNSUPPORTED beyond: use the
+ * rotary = rotate-half over the 64 dims with d_rope (at least seq rows).  seq <= 512 (RQ_EUNSUPPORTED beyond: use the
  * framework's attention). */
 int rq_nb_attention_f16(const void* d_qkv, const int* d_len, const float* d_rope, void* d_ctx, int batch, int seq, int heads, void* stream);
 /* out = LayerNorm(x + res) * gamma + beta over rows of `width` (8..1536, multiple of 8) elements, fp32 statistics; res may be
