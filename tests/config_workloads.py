@@ -79,13 +79,17 @@ def run_config2(n_total: int = 10_000_000, shards: int = 8, B: int = 64, k: int 
 
     s10, r10, rep10 = search_sharded(k)
     s50, r50, rep50 = search_sharded(50)
+    used8 = sum(int(i.get_option("scan8_used")) for i in idxs)
     t0 = time.perf_counter()
     for _ in range(steps):
         search_sharded(k)
     dt = (time.perf_counter() - t0) / steps
+    int8_scan = sum(int(i.get_option("scan8_used")) for i in idxs) - used8 == steps * shards     # every timed search scanned the int8 image
+    row_bytes = 768 if int8_scan else 1536
     out = {"workload": f"{n_total}x768 fp16 in {shards} row shards of {per} on one GPU, batch-{B}, top-{k}: per-shard search -> keys -> device merge",
            "data": "synthetic stand-in (Gaussian unit rows, seeds 1236+shard)", "ms_per_batch": dt * 1e3, "queries_per_s": B / dt,
-           "achieved_GBs": n_total * 1536 / dt / 1e9, "repaired_queries": rep10 + rep50,
+           "scanned": "int8 image of every shard, 768 B per row" if int8_scan else "fp16 rows, 1536 B per row",
+           "achieved_GBs": n_total * row_bytes / dt / 1e9, "repaired_queries": rep10 + rep50,
            "planted_at_rank_1": bool(r10[: len(planted), 0].tolist() == planted and np.allclose(s10[: len(planted), 0], 1.0, atol=1e-6)),
            "top10_is_prefix_of_top50": bool(np.array_equal(r50[:, :k], r10) and np.array_equal(s50[:, :k], s10))}
     if big is not None:
