@@ -48,7 +48,7 @@ def main() -> None:
     ap.add_argument("--event-stride", type=int, default=4, help="HIP events around every n-th scan launch of the timed region")
     ap.add_argument("--scan", choices=("auto", "fp16", "int8"), default="auto",
                     help="corpus operand of the scan: fp16 rows, their int8 image (half the bytes; candidates are still re-scored from "
-                         "the fp16 rows in fp64), or the library's rule (int8 image on shards of 100k rows and more)")
+                         "the fp16 rows in fp64), or the library's rule (int8 image on shards of 200k rows and more)")
     ap.add_argument("--no-hint", action="store_true", help="do not announce the next batch (rq_search_hint_next_device): every call prepares its own queries in a separate launch")
     ap.add_argument("--pipeline", type=int, default=2, help="deferred tails: 1 = on the library's internal stream, 2 = fused into the next scan launch")
     ap.add_argument("--workload", default="headline", choices=["headline", "config2", "config3", "config4"],

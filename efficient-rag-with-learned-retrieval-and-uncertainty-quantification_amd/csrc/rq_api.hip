@@ -429,7 +429,7 @@ static int ensure_x8(rq_index* idx, hipStream_t s) {
 // the shard's share of the int8 scan's bound (unit-query units; the query's own share is added per query by the tail):
 // worst row + the fp32 steps between the exact int32 sum and the bin record (two scale products, two 6-bit truncations)
 static inline float scan8_eps(const rq_index* idx) { return (float)(idx->max_e8 * 1.000001 + 2e-5); }
-#define RQ_SCAN8_MIN_ROWS 100000
+#define RQ_SCAN8_MIN_ROWS 200000
 // ... and k <= 32: at k = 100 the candidate sets of the looser bound make the launch tail-bound on Gaussian data (181 vs 239 us)
 // and overflow the lists on document-structured corpora (runs of similar passages: every query repaired)
 #define RQ_SCAN8_AUTO_MAX_K 32
@@ -505,7 +505,7 @@ extern "C" int rq_stream_release(rq_index* idx, void* stream) {
 // One pass of the pipeline for B queries.  nb < 0: exact scan (every bin re-scored, no corpus scan).
 // may_defer: the caller accepts results that are complete only after rq_search_flush_device ("pipeline" option).
 static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metric, int nb, float* d_scores, int64_t* d_rows,
-                        uint64_t* d_keys, int* d_status, hipStream_t s, bool may_defer = false, bool force_generic = false) {
+                        uint64_t* d_keys, int* d_status, hipStream_t s, bool may_defer = false, bool force_generic = false, bool allow8 = true) {
     if (idx->n == 0) return fill_empty(B, k, d_scores, d_rows, d_keys, d_status, s);
     const int binrows = RQ_BIN_ROWS;
     const int nquads = (int)((idx->n + 63) / 64);
@@ -514,10 +514,11 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     // ... and shards whose rows keep so much of their norm in fp16-subnormal elements that the scan's scores say nothing
     // int8 scan ("scan8": 0 = never, 1 = k <= RQ_SCAN8_AUTO_MAX_K on shards of RQ_SCAN8_MIN_ROWS rows and more -- below that the scan is too short for
     // the saving to outweigh the larger candidate sets the looser bound brings (fused two-stream loop, us per batch int8 / fp16:
-    // 250k rows 35.0 / 59.8, 125k rows 25.0 / 29.0; shorter scans are bound by launch latencies) --, 2 = always): one pass of <= 64 queries over the int8 image of the shard, when its worst row quantises well
+    // 250k rows 35.0 / 59.8, 125k rows 25.0 / 29.0 on Gaussian rows, but 144 / 101 at 125k rows of a document-structured
+    // corpus, profiles/r02_clustered_int8.txt) --, 2 = always): one pass of <= 64 queries over the int8 image of the shard, when its worst row quantises well
     // enough.  Its bound does not involve fp16 subnormals (the image is relative to each row's largest element).
     bool use8 = false;
-    if (idx->scan8 && !idx->scan8_suspended && nb >= 0 && 2 * (int64_t)nb < nbins && B <= 64 && !force_generic && idx->fast_tail && k <= RQ_FAST_MAX_K &&
+    if (allow8 && idx->scan8 && !idx->scan8_suspended && nb >= 0 && 2 * (int64_t)nb < nbins && B <= 64 && !force_generic && idx->fast_tail && k <= RQ_FAST_MAX_K &&
         (idx->scan8 == 2 || (idx->n >= RQ_SCAN8_MIN_ROWS && k <= RQ_SCAN8_AUTO_MAX_K))) {
         if (int r = ensure_x8(idx, s)) return r;
         use8 = idx->max_e8 <= RQ_SCAN8_MAX_ROW_ERR;
@@ -802,10 +803,10 @@ extern "C" int rq_search_fixup_device(rq_index* idx, const float* d_queries, int
     for (int q = 0; q < B; ++q) if (st[q] != 0) bad.push_back(q);
     // The int8 scan bets that real errors stay well below its worst-case bound (threshold multiplier thr_mult8 < 2) and that
     // few rows sit within that bound of the k-th score.  A shard / query mix on which either fails shows up here as repairs:
-    // beyond 1 in 16 checked queries (windows of 1024) the index goes back to the fp16 scan until "scan8" is set again.
+    // beyond 1 in 16 checked queries (windows of 256) the index goes back to the fp16 scan until "scan8" is set again.
     if (idx->x8 && idx->scan8 && !idx->scan8_suspended && B <= 64) {
         idx->scan8_checked += B; idx->scan8_repaired += (int64_t)bad.size();
-        if (idx->scan8_checked >= 1024) {
+        if (idx->scan8_checked >= 256) {
             if (idx->scan8_repaired * 16 > idx->scan8_checked) idx->scan8_suspended = true;
             idx->scan8_checked = idx->scan8_repaired = 0;
         }
@@ -823,14 +824,18 @@ extern "C" int rq_search_fixup_device(rq_index* idx, const float* d_queries, int
         if (int r = ensure(w.fix_status, (size_t)nb_)) return r;
         w.fix_bcap = nb_; w.fix_k = nk;
     }
-    // ladder: 4x wider candidate set, then the full fp64 scan
+    // ladder: (queries that came from the int8 scan: the fp16 scan, whose threshold certifies by construction,) 4x wider
+    // candidate set, then the full fp64 scan
     const int nb1 = std::min(RQ_NB_MAX, 4 * nb_default(idx, k));
-    for (int level = 0; level < 2 && !bad.empty(); ++level) {
+    const bool from8 = idx->x8 && idx->scan8 && B <= 64;
+    for (int level = from8 ? -1 : 0; level < 2 && !bad.empty(); ++level) {
         const int nbq = (int)bad.size();
         for (int i = 0; i < nbq; ++i)
             HIPCHK(hipMemcpyAsync(w.fix_q + (size_t)i * idx->dim, d_queries + (size_t)bad[i] * idx->dim, (size_t)idx->dim * sizeof(float),
                                   hipMemcpyDeviceToDevice, s));
-        if (level == 0) {
+        if (level < 0) {
+            if (int r = run_pipeline(idx, w.fix_q, nbq, k, metric, nb_default(idx, k), w.fix_scores, w.fix_rows, w.fix_keys, w.fix_status, s, false, false, false)) return r;
+        } else if (level == 0) {
             idx->t.widened += nbq;
             // (the fast tail fails only when its candidate lists overflow: the wider pass uses the generic sorted tail)
             if (int r = run_pipeline(idx, w.fix_q, nbq, k, metric, nb1, w.fix_scores, w.fix_rows, w.fix_keys, w.fix_status, s, false, true)) return r;

@@ -130,7 +130,7 @@ int rq_merge_keys_device(const uint64_t* d_keys_in, int n_per_query, int B, int 
  * "use_hint" (0: rq_search_hint_next_device is ignored),
  * "scan8" (calls of <= 64 queries may scan an int8 image of the shard instead of its fp16 rows -- half the bytes per pass;
  *   candidates are still re-scored from the fp16 rows in fp64, so results do not change: 0 = never, 1 = for k <= 32 on shards of
- *   100 000 rows and more (default), 2 = always.  The image (+768 B per row) is built by the first search that wants it; a shard whose
+ *   200 000 rows and more (default), 2 = always.  The image (+768 B per row) is built by the first search that wants it; a shard whose
  *   worst row quantises with more than 3 % relative error keeps the fp16 scan),
  * "thr_mult8" (1.05 .. 2.25, default 1.25: candidate threshold of the int8 scan in units of its worst-case error bound; 2.25
  *   certifies by construction, smaller values re-score fewer rows and leave the rare query whose errors add up to the

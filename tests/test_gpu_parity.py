@@ -1344,7 +1344,7 @@ def test_int8_scan_on_hostile_shards_stays_exact():
 
 
 def test_int8_scan_automatic_rule_and_options():
-    """scan8 = 1 uses the int8 image only for k <= 32 on shards of 100 000 rows and more; thr_mult8 is validated; the always-certifying
+    """scan8 = 1 uses the int8 image only for k <= 32 on shards of 200 000 rows and more; thr_mult8 is validated; the always-certifying
     multiplier 2.25 gives the same rows."""
     import torch
     idx = nat.NativeIndex(768, 0)
