@@ -192,6 +192,21 @@ class BM25Index:
         self._idf = idf
         return idf
 
+    def _np_doc_len(self) -> np.ndarray:
+        cache = getattr(self, "_doc_len_np", None)
+        if cache is None or len(cache) != len(self._doc_len):
+            cache = self._doc_len_np = np.asarray(self._doc_len, dtype=np.float64)
+        return cache
+
+    def _np_postings(self, tok: str, rows: List[int]) -> Tuple[np.ndarray, np.ndarray]:
+        """numpy views of a token's posting list, rebuilt when the list has grown (the lists are append-only).  Converting the
+        Python lists on every query was 70 % of a search over 50 k passages (cProfile: 4.9 of 7.0 ms per query)."""
+        cache = self.__dict__.setdefault("_post_np", {})
+        hit = cache.get(tok)
+        if hit is None or len(hit[0]) != len(rows):
+            hit = cache[tok] = (np.asarray(rows, dtype=np.int64), np.asarray(self._post_tf[tok], dtype=np.float64))
+        return hit
+
     def get_scores(self, tokenized_query: List[str]) -> np.ndarray:
         n_docs = len(self.doc_ids)
         scores = np.zeros(n_docs)
@@ -199,13 +214,12 @@ class BM25Index:
             return scores
         idf = self._ensure_idf()
         avgdl = self._total_len / n_docs
-        doc_len = np.asarray(self._doc_len, dtype=np.float64)
+        doc_len = self._np_doc_len()
         for tok in tokenized_query:
             rows = self._post_rows.get(tok)
             if not rows:
                 continue
-            r = np.asarray(rows, dtype=np.int64)
-            f = np.asarray(self._post_tf[tok], dtype=np.float64)
+            r, f = self._np_postings(tok, rows)
             w = idf.get(tok) or 0
             scores[r] += w * (f * (self.k1 + 1) / (f + self.k1 * (1 - self.b + self.b * doc_len[r] / avgdl)))
         return scores
@@ -279,6 +293,8 @@ class BM25Index:
             self.k1 = data["k1"]
             self.b = data["b"]
         self._post_rows, self._post_tf, self._doc_len, self._total_len = {}, {}, [], 0
+        self.__dict__.pop("_post_np", None)              # numpy views of the posting lists (get_scores): rebuilt on demand
+        self.__dict__.pop("_doc_len_np", None)
         for row, toks in enumerate(self.tokenized_corpus):
             self._index_tokens(row, toks)
         self._snapshot_docs = len(self.doc_ids)

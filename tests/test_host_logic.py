@@ -256,3 +256,26 @@ def test_package_reexports_the_reference_names():
     assert HybridRetriever is si.HybridRetriever and StreamingIndex is si.StreamingIndex and Document is si.Document
     with pytest.raises(AttributeError):
         rag_uq_amd.RetrievalRouter                                               # the router stays in the reference
+
+
+def test_bm25_numpy_posting_views_follow_appends_and_reloads(tmp_path):
+    """BM25Index.get_scores keeps numpy views of the (append-only) posting lists between queries.  A search, an append that
+    extends lists already viewed, and a reload from disk must give exactly what a freshly built index gives."""
+    rng = np.random.default_rng(3)
+    vocab = [f"w{i}" for i in range(300)]
+    texts = [" ".join(rng.choice(vocab, size=int(rng.integers(5, 40)))) for _ in range(600)]
+    docs = [si.Document(id=f"d{i}", text=t) for i, t in enumerate(texts)]
+    queries = [" ".join(rng.choice(vocab, size=6)) for _ in range(25)]
+    inc = si.BM25Index(persist_path=str(tmp_path / "bm25.pkl"))
+    inc.add_documents(docs[:350])
+    first = [inc.search(q, 20) for q in queries]                     # views of the first 350 documents' lists exist now
+    inc.add_documents(docs[350:])
+    fresh = si.BM25Index()
+    fresh.add_documents(docs)
+    assert [inc.search(q, 20) for q in queries] == [fresh.search(q, 20) for q in queries]
+    assert first != [fresh.search(q, 20) for q in queries]            # (the append did change the answers)
+    for q in queries[:5]:
+        assert np.array_equal(inc.get_scores(inc._tokenize(q)), fresh.get_scores(fresh._tokenize(q)))
+    inc.close()
+    again = si.BM25Index(persist_path=str(tmp_path / "bm25.pkl"))
+    assert [again.search(q, 20) for q in queries] == [fresh.search(q, 20) for q in queries]
