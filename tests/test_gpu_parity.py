@@ -365,15 +365,18 @@ def test_next_batch_hint_never_changes_results():
     idx.close()
 
 
-def test_two_streams_with_fused_tails_like_the_multi_gpu_bench():
+@pytest.mark.parametrize("scan8,hints", [(0, False), (2, True)])
+def test_two_streams_with_fused_tails_like_the_multi_gpu_bench(scan8, hints):
     """bench.py at N > 1: two caller streams alternate, each with deferred (fused) tails, keys of 16 batches collected
-    in one buffer before they are read.  Every batch must be exact after the flushes."""
+    in one buffer before they are read.  Every batch must be exact after the flushes -- with the fp16 scan, and with the
+    int8 scan plus next-batch hints per stream (what bench.py does on shards of 200 k rows and more)."""
     import torch
     x16 = orc.synthetic_corpus(50_000, 768, seed=91)
     idx = nat.NativeIndex(768, 0)
     idx.add_f16(x16)
     idx.set_row_offset(1_000_000)
     idx.set_option("pipeline", 2)
+    idx.set_option("scan8", scan8)
     dev = torch.device("cuda:0")
     streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
     B, k, nb = 64, 10, 16
@@ -385,6 +388,8 @@ def test_two_streams_with_fused_tails_like_the_multi_gpu_bench():
     torch.cuda.synchronize()
     for rep in range(2):                                  # second round reuses every workspace
         for i in range(nb):
+            if hints:
+                idx.search_hint_next_device(dq[(i + 2) % nb], B, streams[i % 2].cuda_stream)
             idx.search_device(dq[i], B, k, 0, sc[i], rw[i], keys[i], stt[i], streams[i % 2].cuda_stream)
         for s in streams:
             idx.search_flush_device(s.cuda_stream)
@@ -398,6 +403,9 @@ def test_two_streams_with_fused_tails_like_the_multi_gpu_bench():
             assert np.array_equal(kr, er) and float(np.abs(ks - es).max()) <= SCORE_TOL
         stt.fill_(1); rw.fill_(-7)
         torch.cuda.synchronize()
+    assert int(idx.get_option("scan8_used")) == (2 * nb if scan8 else 0)
+    if hints:
+        assert int(idx.get_option("hints_used")) >= 2 * nb - 4          # all but the first call of each stream and round
     idx.close()
 
 
@@ -1010,6 +1018,9 @@ def test_multi_device_index_persistence_and_row_offset(tmp_path):
     q = orc.synthetic_queries(9, 96, seed=54)
     m.set_row_offset(10_000)
     _check(m, x16, q, 12, row_offset=10_000)
+    m.set_option("scan8", 2)                                     # options reach every device slot; so does the int8 image
+    _check(m, x16, q, 12, row_offset=10_000)
+    assert m.get_option("scan8") == 2 and int(m.get_option("scan8_used")) == 0    # (1 668 rows per slot: no approximate pass at all)
     m.set_row_offset(0)
     m.save(str(tmp_path / "multi"))
     for devs in ([0, 0], [0]):
