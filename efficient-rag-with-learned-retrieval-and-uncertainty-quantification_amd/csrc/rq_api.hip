@@ -124,7 +124,7 @@ extern "C" rq_index* rq_index_create(int dim, int n_devices, const int* device_i
 }
 
 static void free_ws(Workspace& w) {
-    void* p[] = {w.qh, w.q32, w.qn, w.q8, w.qscale8, w.qeps8, w.bins, w.binkeys, w.cand, w.wgmax, w.rowcount, w.thr, w.done, w.ovf, w.fix_q, w.fix_scores, w.fix_rows, w.fix_keys, w.fix_status};
+    void* p[] = {w.qh, w.q32, w.qn, w.q8, w.qscale8, w.qeps8, w.q8lo, w.qeps8s, w.bins, w.binkeys, w.cand, w.wgmax, w.rowcount, w.thr, w.done, w.ovf, w.fix_q, w.fix_scores, w.fix_rows, w.fix_keys, w.fix_status};
     for (void* q : p) if (q) (void)hipFree(q);
     w = Workspace();
 }
@@ -139,6 +139,8 @@ static void free_ctx(StreamCtx& c) {
         if (c.ring_q8[p]) (void)hipFree(c.ring_q8[p]);
         if (c.ring_qscale8[p]) (void)hipFree(c.ring_qscale8[p]);
         if (c.ring_qeps8[p]) (void)hipFree(c.ring_qeps8[p]);
+        if (c.ring_q8lo[p]) (void)hipFree(c.ring_q8lo[p]);
+        if (c.ring_qeps8s[p]) (void)hipFree(c.ring_qeps8s[p]);
     }
     if (c.tail) (void)hipStreamDestroy(c.tail);
     for (int p = 0; p < 2; ++p) {
@@ -269,6 +271,14 @@ extern "C" int rq_index_get_rows_f16(const rq_index* idx, int64_t row_begin, int
 }
 
 // ---- options ---------------------------------------------------------------------------------
+// int8 scan, per class of k (<= 32 / larger): where the adaptive ladder one image -> two images -> fp16 scan starts
+static void scan8_reset_levels(rq_index* idx) {
+    for (int c = 0; c < 2; ++c) {
+        idx->scan8_level[c] = idx->scan8_split < 0 ? c : (idx->scan8_split ? 1 : 0);
+        idx->scan8_checked[c] = idx->scan8_repaired[c] = 0;
+    }
+}
+
 extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     if (!idx || !name) return set_err(RQ_EINVAL, "bad option call");
     if (!idx->shards.empty()) {
@@ -296,7 +306,8 @@ extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     else if (s == "tail_stop") idx->tail_stop = (int)v;
     else if (s == "epi" || s == "fused_epi") idx->epi = (int)v != 0;   // selection form of the 64-query scan (default variant and fused launch): 1 = positions inside the scores, 0 = compare / select
     else if (s == "profile_legacy") idx->profile_legacy = (int)v != 0;   // time scans with hipEventRecord around the launch (round 1) instead of dispatch-attached events
-    else if (s == "scan8") { if (v < 0 || v > 2) return set_err(RQ_EINVAL, "scan8 must be 0, 1 or 2"); idx->scan8 = (int)v; idx->scan8_suspended = false; idx->scan8_checked = idx->scan8_repaired = 0; }   // see run_pipeline
+    else if (s == "scan8") { if (v < 0 || v > 2) return set_err(RQ_EINVAL, "scan8 must be 0, 1 or 2"); idx->scan8 = (int)v; scan8_reset_levels(idx); }   // see run_pipeline
+    else if (s == "scan8_split") { if (v < -1 || v > 1) return set_err(RQ_EINVAL, "scan8_split must be -1, 0 or 1"); idx->scan8_split = (int)v; scan8_reset_levels(idx); }   // see run_pipeline
     else if (s == "thr_mult8") { if (!(v >= 1.05 && v <= 2.25)) return set_err(RQ_EINVAL, "thr_mult8 %g outside 1.05..2.25", v); idx->thr_mult8 = v; }
     else if (s == "tail_local") idx->tail_local = (int)v != 0;   // A/B: 0 = every re-scored row's key goes to the query's global list
     else if (s == "use_hint") idx->use_hint = (int)v != 0;   // 0: rq_search_hint_next_device is ignored (A/B of the folded query preparation)
@@ -334,8 +345,10 @@ extern "C" double rq_get_option(const rq_index* idx, const char* name) {
     if (s == "max_row_norm") return idx->max_row_norm;
     if (s == "scan8") return idx->scan8;
     if (s == "thr_mult8") return idx->thr_mult8;
+    if (s == "scan8_split") return idx->scan8_split;
     if (s == "scan8_row_err") return idx->x8_valid == idx->n && idx->x8 ? idx->max_e8 : -1.0;   // worst row's relative int8 error (-1: image not built)
-    if (s == "scan8_suspended") return idx->scan8_suspended ? 1.0 : 0.0;   // too many repairs behind the int8 scan (rq_search_fixup_device)
+    if (s == "scan8_suspended") return (idx->scan8_level[0] == 2 ? 1.0 : 0.0) + (idx->scan8_level[1] == 2 ? 2.0 : 0.0);   // bit 0: k <= 32, bit 1: larger k
+    if (s == "scan8_level") return idx->scan8_level[0] + 10.0 * idx->scan8_level[1];   // per class: 0 one image, 1 two images, 2 fp16 scan   // too many repairs behind the int8 scan (rq_search_fixup_device)
     if (s == "scan8_used") return (double)idx->scan8_used;   // searches that scanned the int8 image
     if (s == "hints_used") return (double)idx->hints_used;   // searches that found their queries prepared by the launch before them
     if (s == "max_sub_rel") return idx->max_sub_rel;   // largest share of a row's norm that sits in fp16-subnormal elements
@@ -367,6 +380,8 @@ static int ensure_ws(Workspace& w, int bpad, int64_t stride, int64_t m, size_t c
         if (int r = ensure(w.q8, (size_t)bcap * RQ_DPAD)) return r;
         if (int r = ensure(w.qscale8, (size_t)bcap)) return r;
         if (int r = ensure(w.qeps8, (size_t)bcap)) return r;
+        if (int r = ensure(w.q8lo, (size_t)bcap * RQ_DPAD)) return r;
+        if (int r = ensure(w.qeps8s, (size_t)bcap)) return r;
         if (int r = ensure(w.wgmax, (size_t)bcap * RQ_WGMAX_STRIDE)) return r;
         if (int r = ensure(w.rowcount, (size_t)bcap)) return r;
         if (int r = ensure(w.thr, (size_t)bcap)) return r;
@@ -430,9 +445,9 @@ static int ensure_x8(rq_index* idx, hipStream_t s) {
 // worst row + the fp32 steps between the exact int32 sum and the bin record (two scale products, two 6-bit truncations)
 static inline float scan8_eps(const rq_index* idx) { return (float)(idx->max_e8 * 1.000001 + 2e-5); }
 #define RQ_SCAN8_MIN_ROWS 200000
-// ... and k <= 32: at k = 100 the candidate sets of the looser bound make the launch tail-bound on Gaussian data (181 vs 239 us)
-// and overflow the lists on document-structured corpora (runs of similar passages: every query repaired)
-#define RQ_SCAN8_AUTO_MAX_K 32
+// ... and k <= 128 (beyond that the candidate sets of the looser bound outweigh the bytes saved)
+#define RQ_SCAN8_AUTO_MAX_K 128
+#define RQ_SCAN8_SMALL_K 32     // up to here one int8 image per query, beyond two (run_pipeline)
 #define RQ_SCAN8_MAX_ROW_ERR 0.03   // beyond that the candidate sets stop being small: such a shard keeps the fp16 scan
 
 static int fill_empty(int B, int k, float* d_scores, int64_t* d_rows, uint64_t* d_keys, int* d_status, hipStream_t s) {
@@ -518,11 +533,20 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     // corpus, profiles/r02_clustered_int8.txt) --, 2 = always): one pass of <= 64 queries over the int8 image of the shard, when its worst row quantises well
     // enough.  Its bound does not involve fp16 subnormals (the image is relative to each row's largest element).
     bool use8 = false;
-    if (allow8 && idx->scan8 && !idx->scan8_suspended && nb >= 0 && 2 * (int64_t)nb < nbins && B <= 64 && !force_generic && idx->fast_tail && k <= RQ_FAST_MAX_K &&
-        (idx->scan8 == 2 || (idx->n >= RQ_SCAN8_MIN_ROWS && k <= RQ_SCAN8_AUTO_MAX_K))) {
+    const int kclass = k <= RQ_SCAN8_SMALL_K ? 0 : 1;
+    if (allow8 && idx->scan8 && idx->scan8_level[kclass] < 2 && nb >= 0 && 2 * (int64_t)nb < nbins && B <= 64 && !force_generic && idx->fast_tail &&
+        k <= RQ_FAST_MAX_K && (idx->scan8 == 2 || (idx->n >= RQ_SCAN8_MIN_ROWS && k <= RQ_SCAN8_AUTO_MAX_K))) {
         if (int r = ensure_x8(idx, s)) return r;
         use8 = idx->max_e8 <= RQ_SCAN8_MAX_ROW_ERR;
     }
+    // Queries as ONE int8 image or as TWO (value + residual: the query's share of the bound vanishes, every corpus fragment
+    // feeds two MFMAs).  Measured at 1M rows, fused loop: k = 10  132 us per batch with one image, 143-146 with two (the
+    // scan stops being purely HBM-bound); k = 100  189 us with one, 153 with two (a third of the candidate rows).  "scan8_split"
+    // -1 (default): one image for k <= 32, two beyond; 0 / 1: one / two for every k.  That is only where a class STARTS: when
+    // more than 1 in 16 checked queries of a class needed repair, rq_search_fixup_device moves it one step along
+    // one image -> two images -> fp16 scan (clustered corpus + random queries at k = 10: one image 19 of 64 queries repaired,
+    // two images none, 245 us per batch against 275 with the fp16 scan).
+    const bool split8 = use8 && idx->scan8_level[kclass] == 1;
     const bool exact = nb < 0 || 2 * (int64_t)nb >= nbins || (!use8 && idx->eps < 0 && scan_eps(idx, metric) > RQ_EPS_USELESS);
     if (exact) nb = (int)std::min<int64_t>(nbins, INT32_MAX / 64);
     if (!exact && nb > RQ_NB_MAX) return set_err(RQ_EINVAL, "nb %d too large", nb);
@@ -568,6 +592,8 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             if (!cx.ring_q8[p]) HIPCHK(hipMalloc((void**)&cx.ring_q8[p], (size_t)64 * RQ_DPAD));
             if (!cx.ring_qscale8[p]) HIPCHK(hipMalloc((void**)&cx.ring_qscale8[p], (size_t)64 * sizeof(float)));
             if (!cx.ring_qeps8[p]) HIPCHK(hipMalloc((void**)&cx.ring_qeps8[p], (size_t)64 * sizeof(float)));
+            if (!cx.ring_q8lo[p]) HIPCHK(hipMalloc((void**)&cx.ring_q8lo[p], (size_t)64 * RQ_DPAD));
+            if (!cx.ring_qeps8s[p]) HIPCHK(hipMalloc((void**)&cx.ring_qeps8s[p], (size_t)64 * sizeof(float)));
         }
     } else if (piped) {
         if (cx.fused_pending) { if (int r = flush_tails(idx, s)) return r; }
@@ -605,6 +631,8 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     signed char* const q8 = fused ? cx.ring_q8[slot] : w.q8;
     float* const qscale8 = fused ? cx.ring_qscale8[slot] : w.qscale8;
     float* const qeps8 = fused ? cx.ring_qeps8[slot] : w.qeps8;
+    signed char* const q8lo = fused ? cx.ring_q8lo[slot] : w.q8lo;
+    float* const qeps8s = fused ? cx.ring_qeps8s[slot] : w.qeps8s;
     if (use8) idx->scan8_used++;
     // ... unless the previous launch of this stream has already prepared exactly these queries (rq_search_hint_next_device)
     const bool prepared = fused && cx.prepped_q == d_q && cx.prepped_B == B && cx.prepped_slot == slot;
@@ -613,7 +641,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     if (!prepared) {
         RqPrepArgs me{};
         me.q = d_q; me.dim = idx->dim; me.B = B; me.nslots = bpad;
-        me.qh = qh; me.q32pad = q32; me.qnorm64 = qn; me.q8 = q8; me.qscale8 = qscale8; me.qeps8 = qeps8;
+        me.qh = qh; me.q32pad = q32; me.qnorm64 = qn; me.q8 = q8; me.qscale8 = qscale8; me.qeps8 = qeps8; me.q8lo = q8lo; me.qeps8s = qeps8s;
         HIPCHK(rq_prep_queries_launch(me, s));
     }
     // the queries announced for the NEXT call are prepared by extra workgroups of this call's fused launch
@@ -623,6 +651,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
         pa.q = cx.hint_q; pa.dim = idx->dim; pa.B = cx.hint_B; pa.nslots = 64;
         pa.qh = cx.ring_qh[nslot]; pa.q32pad = cx.ring_q32[nslot]; pa.qnorm64 = cx.ring_qn[nslot];
         pa.q8 = cx.ring_q8[nslot]; pa.qscale8 = cx.ring_qscale8[nslot]; pa.qeps8 = cx.ring_qeps8[nslot];
+        pa.q8lo = cx.ring_q8lo[nslot]; pa.qeps8s = cx.ring_qeps8s[nslot];
     }
     // one scan grid for every pass of the call (the tail reads nwg partition maxima per query): the widest pass decides
     const int wg_cu = qb0 > 64 ? 1 : idx->wg_per_cu;   // every pass of more than 64 queries runs one 512-thread workgroup per CU
@@ -634,7 +663,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
         for (int blk = 0, q0 = 0; blk < npass; q0 += pass_q[blk], ++blk) {
             const int qb = pass_q[blk];
             RqScanArgs a;
-            a.i8 = 0; a.qscale = nullptr;
+            a.i8 = 0; a.qscale = nullptr; a.qlo = nullptr;
             a.x = idx->x;
             a.row_scale = scale;
             a.qh = qh + (size_t)q0 * RQ_DPAD;
@@ -646,7 +675,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             a.wgmax = w.wgmax + (size_t)q0 * RQ_WGMAX_STRIDE;
             a.wgmax_stride = RQ_WGMAX_STRIDE;
             if (use8) {
-                a.i8 = 1; a.x = idx->x8; a.row_scale = metric == RQ_METRIC_IP ? idx->scale8_ip : idx->scale8_cos;
+                a.i8 = split8 ? 2 : 1; a.qlo = q8lo; a.x = idx->x8; a.row_scale = metric == RQ_METRIC_IP ? idx->scale8_ip : idx->scale8_cos;
                 a.qh = (const _Float16*)q8; a.qscale = qscale8;
             }
             const bool prof = idx->profile == 1 && idx->ev_used < 16384 && (idx->scan_seq++ % (uint64_t)idx->profile_stride) == 0;
@@ -672,7 +701,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
                 HIPCHK(rq_scan_tail_launch(a, cx.fused_tail, cx.fused_B, pa, nt, grid, idx->epi, s, e0, e1));
             } else if (fused && pa.nslots) {   // first call of a loop: no tail to carry yet, but queries to prepare
                 RqTailArgs none{};
-                none.nbins = nbins; none.m = none.k = 1; none.thr_mult = 2.25f;
+                none.nbins = nbins; none.m = none.k = 1; none.thr_mult = 2.25f; none.thr_slack = 0.f;
                 HIPCHK(rq_scan_tail_launch(a, none, 0, pa, nt, grid, idx->epi, s, e0, e1));
             } else if (fused) HIPCHK(rq_scan_launch(a, 3, 1, 2, 4, nt, grid, idx->epi, s, e0, e1));
             else if (qb == 256) HIPCHK(rq_scan_wide_launch(a, idx->wide256, 256, nt, grid, s, e0, e1));
@@ -699,8 +728,13 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             ta.wgmax = w.wgmax; ta.wgmax_stride = RQ_WGMAX_STRIDE; ta.nwg = grid;
             ta.m = (int)std::min<int64_t>(k, idx->n); ta.metric = metric; ta.k = k;
             ta.eps = use8 ? scan8_eps(idx) : scan_eps(idx, metric);
-            ta.qeps = use8 ? qeps8 : nullptr;
+            ta.qeps = use8 ? (split8 ? qeps8s : qeps8) : nullptr;
+            // int8 scan: T = P - bound - slack.  The slack covers how far the k-th EXACT score may sit below P (= a k-th largest
+            // APPROXIMATE score, biased upward by the errors of the rows that won); it is (thr_mult8 - 1) x the larger of the
+            // query's own bound and the one-image bound of a typical query -- also when the queries are split (their bound is
+            // smaller, the rows' errors are not)
             ta.thr_mult = use8 ? (float)idx->thr_mult8 : 2.25f;
+            ta.thr_slack = use8 ? (float)(idx->max_e8 + 0.009) : 0.f;
             ta.local_topk = idx->tail_local;
             ta.max_row_norm = (float)(idx->max_row_norm * (1.0 + 1e-6)); ta.row_offset = idx->row_offset;
             ta.cand = w.cand; ta.rowcount = w.rowcount; ta.done = w.done; ta.ovf = w.ovf;
@@ -803,12 +837,14 @@ extern "C" int rq_search_fixup_device(rq_index* idx, const float* d_queries, int
     for (int q = 0; q < B; ++q) if (st[q] != 0) bad.push_back(q);
     // The int8 scan bets that real errors stay well below its worst-case bound (threshold multiplier thr_mult8 < 2) and that
     // few rows sit within that bound of the k-th score.  A shard / query mix on which either fails shows up here as repairs:
-    // beyond 1 in 16 checked queries (windows of 256) the index goes back to the fp16 scan until "scan8" is set again.
-    if (idx->x8 && idx->scan8 && !idx->scan8_suspended && B <= 64) {
-        idx->scan8_checked += B; idx->scan8_repaired += (int64_t)bad.size();
-        if (idx->scan8_checked >= 256) {
-            if (idx->scan8_repaired * 16 > idx->scan8_checked) idx->scan8_suspended = true;
-            idx->scan8_checked = idx->scan8_repaired = 0;
+    // beyond 1 in 16 checked queries (windows of 256) the class of k moves one step along one image -> two images -> fp16 scan,
+    // until "scan8" / "scan8_split" is set again.
+    const int kclass = k <= RQ_SCAN8_SMALL_K ? 0 : 1;
+    if (idx->x8 && idx->scan8 && idx->scan8_level[kclass] < 2 && B <= 64) {
+        idx->scan8_checked[kclass] += B; idx->scan8_repaired[kclass] += (int64_t)bad.size();
+        if (idx->scan8_checked[kclass] >= 256) {
+            if (idx->scan8_repaired[kclass] * 16 > idx->scan8_checked[kclass]) idx->scan8_level[kclass]++;
+            idx->scan8_checked[kclass] = idx->scan8_repaired[kclass] = 0;
         }
     }
     if (bad.empty()) return 0;

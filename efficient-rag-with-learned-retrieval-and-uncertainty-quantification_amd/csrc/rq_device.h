@@ -120,7 +120,7 @@ __device__ __forceinline__ double rq_wave_sum(double v) {
 // Query preparation of one query slot by one 256-thread workgroup (thread t owns elements t, 256 + t, 512 + t):
 // fp64 norm, qh = fp16(q / |q| * 2^12) (the factor: rq_select.hip), zero padded raw copy, slots >= B all zero; and, when
 // wanted, the int8 image of the query with its scale and its measured quantisation error (rq_kernels.h RqPrepArgs).
-// `part` = 12 doubles of LDS.
+// `part` = 16 doubles of LDS.
 template <class PrepArgs>
 __device__ __forceinline__ void rq_prep_body(const PrepArgs& a, const int qi, double* part) {
     const int tid = threadIdx.x;
@@ -152,22 +152,30 @@ __device__ __forceinline__ void rq_prep_body(const PrepArgs& a, const int qi, do
         const float amax = (float)fmax(fmax(part[4], part[5]), fmax(part[6], part[7]));
         const bool live = finite && amax > 0.f;
         const float sq = live ? amax / 127.f : 0.f, inv = live ? 127.f / amax : 0.f;
-        double err = 0.0;
+        const float slo = sq / 254.f, invlo = live ? 254.f / sq : 0.f;   // residual step: |q - sq r| <= sq / 2 = 127 slo
+        double err = 0.0, errs = 0.0;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const float r = fminf(fmaxf(rintf(v[p] * inv), -127.f), 127.f);
             const double d = live ? (double)v[p] - (double)sq * (double)r : 0.0;
             err += d * d;
+            const float rl = fminf(fmaxf(rintf((float)d * invlo), -127.f), 127.f);
+            const double ds = live ? d - (double)slo * (double)rl : 0.0;
+            errs += ds * ds;
             a.q8[(size_t)qi * RQ_DPAD + p * 256 + tid] = (signed char)(int)r;
+            a.q8lo[(size_t)qi * RQ_DPAD + p * 256 + tid] = (signed char)(int)rl;
         }
         err = rq_wave_sum(err);
-        if ((tid & 63) == 0) part[8 + (tid >> 6)] = err;
+        errs = rq_wave_sum(errs);
+        if ((tid & 63) == 0) { part[8 + (tid >> 6)] = err; part[12 + (tid >> 6)] = errs; }
         __syncthreads();
         if (tid == 0) {
             const double e = sqrt((part[8] + part[9]) + (part[10] + part[11]));
+            const double es = sqrt((part[12] + part[13]) + (part[14] + part[15]));
             a.qscale8[qi] = live ? (float)((double)sq / nrm) : 1.f;
             // rounded up to fp32; +inf for a non-finite query (never certified from the approximate pass)
             a.qeps8[qi] = !finite ? __builtin_huge_valf() : (live ? (float)(e / nrm) * 1.000001f + 1e-30f : 0.f);
+            a.qeps8s[qi] = !finite ? __builtin_huge_valf() : (live ? (float)(es / nrm) * 1.000001f + 1e-30f : 0.f);
         }
     }
 }

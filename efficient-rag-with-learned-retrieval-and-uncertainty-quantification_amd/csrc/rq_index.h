@@ -44,6 +44,8 @@ struct Workspace {
     signed char* q8 = nullptr;    // int8 scan: the queries' int8 image, their scales and quantisation errors (rq_kernels.h RqPrepArgs)
     float* qscale8 = nullptr;
     float* qeps8 = nullptr;
+    signed char* q8lo = nullptr;  // second int8 image (the residual) and the error left after both
+    float* qeps8s = nullptr;
     uint2* bins = nullptr;        // [bcap][bins_stride] scan output: one record per (query, quad), see rq_device.h
     uint64_t* binkeys = nullptr;
     uint64_t* cand = nullptr;
@@ -84,6 +86,8 @@ struct StreamCtx {
     signed char* ring_q8[3] = {nullptr, nullptr, nullptr};
     float* ring_qscale8[3] = {nullptr, nullptr, nullptr};
     float* ring_qeps8[3] = {nullptr, nullptr, nullptr};
+    signed char* ring_q8lo[3] = {nullptr, nullptr, nullptr};
+    float* ring_qeps8s[3] = {nullptr, nullptr, nullptr};
     const float* hint_q = nullptr;      // queries announced for the next fused call, not yet prepared
     int hint_B = 0;
     const float* prepped_q = nullptr;   // queries a launch has already prepared ...
@@ -111,13 +115,15 @@ struct rq_index {
     double* d_maxnorm = nullptr;   // device: bits of the running maxima {row norm, relative, absolute fp16-subnormal mass of a row}
     double max_row_norm = 0.0, max_sub_rel = 0.0, max_sub_abs = 0.0;
     unsigned long long* dbg_stamps = nullptr;   // development (rq_debug_stamps)
-    bool scan8_suspended = false;  // rq_search_fixup_device saw too many repairs behind the int8 scan
-    int64_t scan8_checked = 0, scan8_repaired = 0;
+    // rq_search_fixup_device saw too many repairs behind the int8 scan; kept apart for k <= 32 ([0]) and larger k ([1])
+    // per class: 0 = one int8 image per query, 1 = two images, 2 = suspended (fp16 scan); escalated by rq_search_fixup_device
+    int scan8_level[2] = {0, 1};
+    int64_t scan8_checked[2] = {0, 0}, scan8_repaired[2] = {0, 0};
     int64_t scan8_used = 0;        // searches that scanned the int8 image
     int64_t hints_used = 0;        // rq_search_hint_next_device: searches that skipped their preparation launch
     uint64_t scan_seq = 0;         // scan launches seen while profile = 1 (every profile_stride-th one is timed)
     // options
-    int ring = 3, prefetch = 1, kstage = 2, wide_batch = 1, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, profile_stride = 1, scan_nostore = 0, fast_tail = 1, pipeline = 0, tail_stop = 0, poison_cand = 0, wide128 = 0, wide256 = 11, epi = 1, use_hint = 1, profile_legacy = 0, scan8 = 1, tail_local = 1;
+    int ring = 3, prefetch = 1, kstage = 2, wide_batch = 1, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, profile_stride = 1, scan_nostore = 0, fast_tail = 1, pipeline = 0, tail_stop = 0, poison_cand = 0, wide128 = 0, wide256 = 11, epi = 1, use_hint = 1, profile_legacy = 0, scan8 = 1, tail_local = 1, scan8_split = -1;
     double thr_mult8 = 1.25;       // int8 scan: threshold = P - thr_mult8 * bound (rq_tail_body.h)
     double eps = -1.0;
     std::map<hipStream_t, StreamCtx> ctx;

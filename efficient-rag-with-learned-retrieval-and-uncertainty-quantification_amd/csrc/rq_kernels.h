@@ -16,8 +16,11 @@ struct RqScanArgs {
     int wgmax_stride;         // >= grid
     // int8 scan (i8 = 1): x = the int8 image of the shard [rows_padded][768], row_scale = s_row / ||row|| (pad entries NaN),
     // qh = int8 queries [QB][768], qscale[QB] = s_query / ||query||; approximate score = int32 sum * row_scale * qscale
+    // i8 = 2: the queries come as TWO int8 images (q = s (254 q_hi + q_lo), rq_prep_body): qh = q_hi, qlo = q_lo, approximate
+    // score = (254 * sum_hi + sum_lo) * row_scale * qscale / 254 -- the query's quantisation error all but disappears from the bound
     int i8;
     const float* qscale;
+    const void* qlo;
 };
 #define RQ_WGMAX_STRIDE 1024   // scan grids never exceed this many workgroups
 
@@ -51,6 +54,8 @@ struct RqPrepArgs {
     // qscale8[slot] = s / ||q|| (1 for a zero / unused / non-finite query); qeps8[slot] = ||q - s q8|| / ||q||, the
     // query's share of the certificate's error bound (+inf for a non-finite query)
     signed char* q8; float* qscale8; float* qeps8;
+    // second int8 image of the residual: r = q - s q8, q8lo = round(r / (s / 254)); qeps8s[slot] = ||q - s (q8 + q8lo / 254)|| / ||q||
+    signed char* q8lo; float* qeps8s;
 };
 hipError_t rq_prep_queries_launch(const RqPrepArgs& a, hipStream_t stream);   // a.nslots workgroups
 
@@ -120,7 +125,8 @@ struct RqTailArgs {
     float* out_scores; int64_t* out_rows; uint64_t* out_keys; int* out_status;
     const float* qeps;                             // per query error share e_q (int8 scan): bound = e_q (1 + eps) + eps; null = eps alone
     int local_topk;                                // 1: a workgroup with more than k row jobs publishes only its own k best keys (rq_tail_body.h)
-    float thr_mult;                                // threshold T = P - thr_mult * bound (2.25 always certifies; less = fewer candidates, may not)
+    float thr_mult;                                // threshold T = P - bound - (thr_mult - 1) * max(bound, thr_slack): 2.25 always
+    float thr_slack;                               //   certifies; less = fewer candidates, the rare query is repaired (rq_tail_body.h)
     unsigned long long* dbg;                       // development: per-workgroup (start, end) wall-clock stamps of the fused launch, or null
     int stop_after;                                // development: 0 = full kernel, 1..4 = return after phase A..D
 };

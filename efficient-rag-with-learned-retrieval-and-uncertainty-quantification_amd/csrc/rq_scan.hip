@@ -57,12 +57,15 @@ __device__ __forceinline__ void rq_wait_vmcnt() {
 //     (12 KiB, the byte geometry of the fp16 half-row stage, so DMA, swizzle and LDS reads are the same code), every stage
 //     ends a tile, and the per-query scale is applied once per quad.  Half the HBM bytes per row; the certificate's bound is
 //     the quantisation error measured at add / preparation time (csrc/rq_api.hip scan8_eps).
-template <int S, bool NT, int PF, int KS, int QW, int EPI = 0, bool I8 = false>
+//     I8 = 2: the queries are TWO int8 images (value and residual, q = s (254 q_hi + q_lo)); every corpus fragment feeds two
+//     MFMAs and the score is (254 sum_hi + sum_lo) * scales: the query's share of the error bound drops from ~0.008 to ~3e-5
+//     for twice the (idle) matrix-core work and no extra bytes.
+template <int S, bool NT, int PF, int KS, int QW, int EPI = 0, int I8 = 0>
 __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, const int G) {
     static_assert(S >= 2 && S <= 8, "ring depth");
     static_assert(PF == 1 || PF == 4 || PF == 6 || PF == 12, "fragment prefetch group");
     static_assert(KS == 1 || KS == 2, "stages per tile");
-    static_assert(!I8 || (KS == 2 && EPI == 1), "int8 scan: built for the half-row stage geometry and the med3 selection");
+    static_assert(I8 == 0 || (KS == 2 && EPI == 1), "int8 scan: built for the half-row stage geometry and the med3 selection");
     constexpr int ROWB = I8 ? RQ_DPAD : RQ_DPAD * 2;   // bytes per corpus row
     constexpr int KL = I8 ? 1 : KS;                // stages per tile
     constexpr int CH = 96 / KS;                    // 16-byte chunks per stage row
@@ -134,15 +137,24 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
     //      int8: B[k = 16*kg + j][col = r16] of k-step s == q8[16*wave + r16][64*s + 16*kg + j], 12 fragments
     constexpr int NQF = I8 ? 12 : 24;
     rq_half8 qf[NQF];   // (int8: the same 16 bytes per fragment, reinterpreted at the MFMA)
+    rq_half8 ql[I8 == 2 ? 12 : 1];   // I8 = 2: fragments of the residual image
     {
         const rq_half8* qsrc = (const rq_half8*)((const char*)a.qh + (size_t)(16 * wave + r16) * ROWB + 16 * kg);
 #pragma unroll
         for (int s = 0; s < NQF; ++s) qf[s] = qsrc[4 * s];
 #pragma unroll
         for (int s = 0; s < NQF; ++s) asm volatile("" : "+v"(qf[s]));   // ordinary loads retired before the main loop
+        if constexpr (I8 == 2) {
+            const rq_half8* lsrc = (const rq_half8*)((const char*)a.qlo + (size_t)(16 * wave + r16) * ROWB + 16 * kg);
+#pragma unroll
+            for (int s = 0; s < 12; ++s) ql[s] = lsrc[4 * s];
+#pragma unroll
+            for (int s = 0; s < 12; ++s) asm volatile("" : "+v"(ql[s]));
+        }
     }
     float qsc = 1.f;    // int8: s_q / |q| of this lane's query (rq_prep_body), applied once per quad
     if (I8) qsc = a.qscale[16 * wave + r16];
+    if (I8 == 2) qsc *= (1.f / 254.f);
 
     // Finished records wait in LDS and leave in ONE burst per SQ quads (normally once, at the end of the
     // workgroup's range).  Stores inside the streaming loop are what this kernel is sensitive to: every store
@@ -169,7 +181,7 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             rq_float4 acc = {0.f, 0.f, 0.f, 0.f};
-            rq_int4 iacc = {0, 0, 0, 0};
+            rq_int4 iacc = {0, 0, 0, 0}, lacc = {0, 0, 0, 0};
 #pragma unroll
             for (int kh = 0; kh < KL; ++kh) {
                 const int st = lq * NSTQ + t * KL + kh;
@@ -186,14 +198,16 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
                     for (int s = 0; s < PF; ++s) av[s] = *(const rq_half8*)(sb + (rbase0 ^ (unsigned)(((g + s) & 3) << 6)) + (((g + s) & ~3) << 6));
 #pragma unroll
                     for (int s = 0; s < PF; ++s) {
-                        if constexpr (I8) iacc = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(rq_int4, av[s]), __builtin_bit_cast(rq_int4, qf[g + s]), iacc, 0, 0, 0);
-                        else acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[s], qf[kh * MF + g + s], acc, 0, 0, 0);
+                        if constexpr (I8 != 0) {
+                            iacc = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(rq_int4, av[s]), __builtin_bit_cast(rq_int4, qf[g + s]), iacc, 0, 0, 0);
+                            if constexpr (I8 == 2) lacc = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(rq_int4, av[s]), __builtin_bit_cast(rq_int4, ql[g + s]), lacc, 0, 0, 0);
+                        } else acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[s], qf[kh * MF + g + s], acc, 0, 0, 0);
                     }
                 }
             }
-            if constexpr (I8) {   // |sum| <= 768 * 127 * 127 < 2^24: the conversion is exact
+            if constexpr (I8 != 0) {   // |sum| <= 768 * 127 * 127 < 2^24: the conversions are exact
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = (float)iacc[i];
+                for (int i = 0; i < 4; ++i) acc[i] = I8 == 2 ? fmaf((float)iacc[i], 254.f, (float)lacc[i]) : (float)iacc[i];
             }
             // tile epilogue: D[row = 4*kg + i][query = r16]
             const rq_float4 nv = *(const rq_float4*)(nrow + t * 64);
@@ -217,7 +231,7 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
             }
         }
         if (EPI == 1) {
-            if constexpr (I8) {   // the query's scale (positive: order unchanged); the positions ride through it
+            if constexpr (I8 != 0) {   // the query's scale (positive: order unchanged); the positions ride through it
                 m1 = rq_scale_pos(m1, qsc); m2 = rq_scale_pos(m2, qsc); m3 = rq_scale_pos(m3, qsc);
             }
             // positions become complete (row group of the lane); the four lanes that share the query insert each other's triples
@@ -272,10 +286,10 @@ static constexpr size_t rq_scan_lds_bytes(int S, int KS, int QW) {
     return (size_t)S * (24576 / KS) + 512 + (size_t)16 * QW * rq_stage_quads(QW) * 8;
 }
 
-// EPI of the kernels: 0 / 1 = selection form of the fp16 scan, 2 = the int8 scan (selection form 1)
+// EPI of the kernels: 0 / 1 = selection form of the fp16 scan, 2 = the int8 scan (selection form 1), 3 = int8 with split queries
 template <int S, bool NT, int PF, int OCC, int KS, int QW, int EPI>
 __global__ __launch_bounds__(64 * QW, OCC) void rq_scan_kernel(RqScanArgs a) {
-    rq_scan_body<S, NT, PF, KS, QW, (EPI == 2 ? 1 : EPI), EPI == 2>(a, (int)blockIdx.x, (int)gridDim.x);
+    rq_scan_body<S, NT, PF, KS, QW, (EPI >= 2 ? 1 : EPI), (EPI >= 2 ? EPI - 1 : 0)>(a, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Fused launch: workgroups [0, scan_grid) scan the corpus for THIS batch, the others run the tail (threshold, fp64
@@ -294,7 +308,7 @@ __global__ __launch_bounds__(256, 3) void rq_scan_tail_kernel(RqScanArgs sa, RqT
     const int nprep = pa.nslots;
     const int ntail = (int)gridDim.x - scan_grid - nprep;
     if (bid < scan_grid) {
-        rq_scan_body<3, NT, 1, 2, 4, (EPI == 2 ? 1 : EPI), EPI == 2>(sa, bid, scan_grid);
+        rq_scan_body<3, NT, 1, 2, 4, (EPI >= 2 ? 1 : EPI), (EPI >= 2 ? EPI - 1 : 0)>(sa, bid, scan_grid);
     } else if (bid < scan_grid + ntail) {
         const int t = bid - scan_grid;
         rq_tail_body<NV>(ta, t % tail_chunks, t / tail_chunks, tail_chunks, *reinterpret_cast<RqTailLds*>(rq_smem));
@@ -338,6 +352,7 @@ static hipError_t rq_scan_launch_r(const RqScanArgs& a, bool nt, int grid, hipSt
 // epi = 1 (selection with positions inside the scores) exists for the default variant (ring 3, prefetch 1, half-row stages, 4 waves)
 hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int ks, int qw, bool nt, int grid, int epi, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
     if (grid <= 0) return hipErrorInvalidValue;
+    if (a.i8 == 2) return (S == 3 && pf == 1 && ks == 2 && qw == 4) ? rq_scan_launch_r<3, 1, 3, 2, 4, 3>(a, nt, grid, stream, e0, e1) : hipErrorInvalidValue;
     if (a.i8) return (S == 3 && pf == 1 && ks == 2 && qw == 4) ? rq_scan_launch_r<3, 1, 3, 2, 4, 2>(a, nt, grid, stream, e0, e1) : hipErrorInvalidValue;
     if (epi && S == 3 && pf == 1 && ks == 2 && qw == 4) return rq_scan_launch_r<3, 1, 3, 2, 4, 1>(a, nt, grid, stream, e0, e1);
 #define RQ_CASE(SS, PP, OO, KK, QQ) if (S == SS && pf == PP && ks == KK && qw == QQ) return rq_scan_launch_r<SS, PP, OO, KK, QQ>(a, nt, grid, stream, e0, e1);
@@ -397,6 +412,7 @@ static hipError_t rq_scan_tail_launch_e(const RqScanArgs& sa, const RqTailArgs& 
 hipError_t rq_scan_tail_launch(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, const RqPrepArgs& pa, bool nt, int scan_grid, int epi, hipStream_t stream,
                                hipEvent_t e0, hipEvent_t e1) {
     if (pa.nslots < 0 || pa.nslots > 64) return hipErrorInvalidValue;
+    if (sa.i8 == 2) return rq_scan_tail_launch_e<3>(sa, ta, tail_B, pa, nt, scan_grid, stream, e0, e1);
     if (sa.i8) return rq_scan_tail_launch_e<2>(sa, ta, tail_B, pa, nt, scan_grid, stream, e0, e1);
     return epi ? rq_scan_tail_launch_e<1>(sa, ta, tail_B, pa, nt, scan_grid, stream, e0, e1)
                : rq_scan_tail_launch_e<0>(sa, ta, tail_B, pa, nt, scan_grid, stream, e0, e1);

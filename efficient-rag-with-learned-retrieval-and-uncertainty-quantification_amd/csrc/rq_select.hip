@@ -151,7 +151,7 @@ hipError_t rq_pad_f16_launch(const void* src, int dim, int64_t n, void* dst, hip
 // 2^-26 of the unit query -- at most sqrt(768) * 2^-26 = 4e-7 of score error, against 1.7e-3 without the scaling.
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rq_prep_queries_kernel(RqPrepArgs a) {
-    __shared__ double part[12];
+    __shared__ double part[16];
     rq_prep_body(a, (int)blockIdx.x, part);
 }
 hipError_t rq_prep_queries_launch(const RqPrepArgs& a, hipStream_t stream) {

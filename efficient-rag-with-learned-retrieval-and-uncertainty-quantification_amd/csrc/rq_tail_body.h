@@ -93,7 +93,10 @@ __device__ __forceinline__ void rq_tail_body(const RqTailArgs& a, const int chun
             if (prefix > rq_mono32(NEG_INF)) {
                 const float P = rq_unmono32(prefix);
                 const float e = a.metric == 0 ? eps_q : eps_q * a.max_row_norm;
-                T0 = P - a.thr_mult * e - 4e-6f * fabsf(P);   // margin: the 1e-6 relative slack of the certificate and fp32 rounding
+                // T = P - e - (thr_mult - 1) max(e, thr_slack): thr_mult 2.25 certifies by construction (T + e < P - e <= s_k); the int8
+                // scan runs with less, the slack then being measured against the bound of a typical one-image query (rq_api.hip)
+                const float es = fmaxf(e, a.metric == 0 ? a.thr_slack : a.thr_slack * a.max_row_norm);
+                T0 = P - e - (a.thr_mult - 1.f) * es - 4e-6f * fabsf(P);   // margin: the 1e-6 relative slack of the certificate and fp32 rounding
             }
             thr_s = T0;
         }

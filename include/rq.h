@@ -129,17 +129,21 @@ int rq_merge_keys_device(const uint64_t* d_keys_in, int n_per_query, int B, int 
  * "epi" (selection form of the 64-query scan: 1 = row positions inside the scores, 0 = compare / select),
  * "use_hint" (0: rq_search_hint_next_device is ignored),
  * "scan8" (calls of <= 64 queries may scan an int8 image of the shard instead of its fp16 rows -- half the bytes per pass;
- *   candidates are still re-scored from the fp16 rows in fp64, so results do not change: 0 = never, 1 = for k <= 32 on shards of
+ *   candidates are still re-scored from the fp16 rows in fp64, so results do not change: 0 = never, 1 = for k <= 128 on shards of
  *   200 000 rows and more (default), 2 = always.  The image (+768 B per row) is built by the first search that wants it; a shard whose
  *   worst row quantises with more than 3 % relative error keeps the fp16 scan),
- * "thr_mult8" (1.05 .. 2.25, default 1.25: candidate threshold of the int8 scan in units of its worst-case error bound; 2.25
- *   certifies by construction, smaller values re-score fewer rows and leave the rare query whose errors add up to the
- *   repair path of rq_search_fixup_device; when more than 1 in 16 checked queries need repair the index stops using the
- *   image until "scan8" is set again),
+ * "scan8_split" (-1 = default: the queries reach the int8 scan as one int8 image for k <= 32 and as two -- value and residual,
+ *   twice the matrix-core work, a third of the candidate rows -- for larger k; 0 / 1: one / two images for every k),
+ * "thr_mult8" (1.05 .. 2.25, default 1.25: candidate threshold of the int8 scan, T = P - bound - (thr_mult8 - 1) * max(bound,
+ *   typical one-image bound); 2.25 certifies by construction, smaller values re-score fewer rows and leave the rare query
+ *   whose errors add up to the repair path of rq_search_fixup_device.  When more than 1 in 16 checked queries of a class of
+ *   k (<= 32 / larger) needed repair, that class moves one step along one image -> two images -> fp16 scan, until "scan8" or
+ *   "scan8_split" is set again),
  * "tail_local" (A/B hook, default 1: a tail workgroup with more than k re-scored rows publishes only its own k best keys),
  * "poison_cand" (test hook: candidate lists are filled with 0xff..ff keys before every tail).
  * Read-only: "scan8_used" (searches that scanned the int8 image), "scan8_row_err" (worst row's relative int8 error, -1 = image
- * not built), "scan8_suspended", "hints_used" (searches that found their queries prepared, see rq_search_hint_next_device), "max_row_norm", "max_sub_rel" / "max_sub_abs" (largest share of a stored row that sits in fp16-subnormal elements,
+ * not built), "scan8_level" (ladder position: class k <= 32 + 10 * class of larger k; 0 one image, 1 two images, 2 fp16 scan),
+ * "scan8_suspended" (bit 0 / 1: that class is back at the fp16 scan), "hints_used" (searches that found their queries prepared, see rq_search_hint_next_device), "max_row_norm", "max_sub_rel" / "max_sub_abs" (largest share of a stored row that sits in fp16-subnormal elements,
  * which the matrix cores flush), "eps_cosine" / "eps_ip" (the certificate's bound including that term). */
 int rq_set_option(rq_index* idx, const char* name, double value);
 double rq_get_option(const rq_index* idx, const char* name);

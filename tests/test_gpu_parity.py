@@ -1037,7 +1037,7 @@ def test_multi_device_index_persistence_and_row_offset(tmp_path):
     tiny.close(); empty.close()
     with pytest.raises(nat.RqError, match="multi-device"):
         m.search_device(8, 1, 1, 0, 8, 8, None, 8)          # (dummy non-null addresses: refused before anything is touched)
-    assert m.timing()["queries"] == 9
+    assert m.timing()["queries"] == 18                  # two searches of 9 queries (the parent counts the calls)
     m.close()
 
 
@@ -1238,13 +1238,15 @@ def test_baseline_config0_10k_passages_100_queries_top10(tmp_path):
 
 
 # ---- int8 scan (option "scan8"): half the corpus bytes per pass, same exact answers -----------------------------------
-def test_int8_scan_matches_oracle_100k(corpus100k):
+@pytest.mark.parametrize("split", [0, 1])
+def test_int8_scan_matches_oracle_100k(corpus100k, split):
     """Option scan8: calls of <= 64 queries scan the int8 image of the shard (csrc/rq_scan.hip I8, per-row and per-query
     scales, exact int32 sums) and re-score the candidates from the fp16 rows in fp64 as before.  The certificate's bound is
     the MEASURED quantisation error of the worst row plus the query's own.  Rows identical to the oracle, scores within
     1e-6, for cosine and inner product, k = 1 .. 100, ragged batches, a zero query, a query equal to a stored row."""
     idx, x16 = corpus100k
     idx.set_option("scan8", 2)               # 2 = also on shards below the size the automatic rule (1) asks for
+    idx.set_option("scan8_split", split)     # 1: two int8 images per query (value + residual), twice the MFMAs, tighter bound
     try:
         before = int(idx.get_option("scan8_used"))
         for B, k in ((64, 10), (1, 1), (17, 10), (64, 100), (5, 50)):
@@ -1263,6 +1265,7 @@ def test_int8_scan_matches_oracle_100k(corpus100k):
         assert int(idx.get_option("scan8_used")) == before + 6
     finally:
         idx.set_option("scan8", 1)
+        idx.set_option("scan8_split", -1)
 
 
 def _planted_outlier_rows(n, seed):
@@ -1336,26 +1339,25 @@ def test_int8_scan_on_hostile_shards_stays_exact():
     qc = xc[::1000][:48].astype(np.float32) + 0.05 * orc.synthetic_queries(48, 768, seed=9)
     _check(idx, xc, qc, 10)
     assert int(idx.get_option("scan8_used")) >= 1
-    # ... and when most queries need repairing (every query sits inside a cluster of ~900 near-identical scores), the index
-    # gives the int8 scan up after a window of 1024 checked queries; results stay exact throughout
-    assert idx.get_option("scan8_suspended") == 0.0
+    # ... and when most queries need repairing (every query sits inside a cluster of ~900 near-identical scores), the class of
+    # k moves along one image -> two images -> fp16 scan after windows of 256 checked queries; results stay exact throughout
+    assert idx.get_option("scan8_level") == 10.0                   # k <= 32: one image, larger k: two images
     for rep in range(24):
         qr = xc[rep::97][:64].astype(np.float32)
         s_, r_ = idx.search(qr, 10)
         if rep % 8 == 0:
             gs, gr = orc.dense_topk(qr, xc, 10)
             assert np.array_equal(r_, gr) and float(np.abs(s_ - gs).max()) <= SCORE_TOL
-    assert idx.get_option("scan8_suspended") == 1.0
-    used = int(idx.get_option("scan8_used"))
-    idx.search(qc, 10)
-    assert int(idx.get_option("scan8_used")) == used          # suspended: the fp16 scan
-    idx.set_option("scan8", 2)                                # setting the option again lifts the suspension
-    assert idx.get_option("scan8_suspended") == 0.0
+    level = int(idx.get_option("scan8_level")) % 10
+    assert level >= 1, level                                        # at least the step to two-image queries was taken
+    assert (int(idx.get_option("scan8_suspended")) & 1) == (1 if level == 2 else 0)
+    idx.set_option("scan8", 2)                                      # setting the option again starts over
+    assert idx.get_option("scan8_level") == 10.0 and idx.get_option("scan8_suspended") == 0.0
     idx.close()
 
 
 def test_int8_scan_automatic_rule_and_options():
-    """scan8 = 1 uses the int8 image only for k <= 32 on shards of 200 000 rows and more; thr_mult8 is validated; the always-certifying
+    """scan8 = 1 uses the int8 image only for k <= 128 on shards of 200 000 rows and more; thr_mult8 is validated; the always-certifying
     multiplier 2.25 gives the same rows."""
     import torch
     idx = nat.NativeIndex(768, 0)
@@ -1365,15 +1367,19 @@ def test_int8_scan_automatic_rule_and_options():
     idx.set_option("scan8", 1)
     _check(idx, x16, q, 10)
     assert int(idx.get_option("scan8_used")) == 1
-    _check(idx, x16, q, 100)                   # the automatic rule stops at k = 32
-    assert int(idx.get_option("scan8_used")) == 1
+    _check(idx, x16, q, 100)                   # k = 33 .. 128: the int8 image with two-image queries
+    assert int(idx.get_option("scan8_used")) == 2
+    _check(idx, x16, q, 200)                   # the automatic rule stops at k = 128
+    assert int(idx.get_option("scan8_used")) == 2
     idx.set_option("thr_mult8", 2.25)
     _check(idx, x16, q, 10)
-    assert int(idx.get_option("scan8_used")) == 2
+    assert int(idx.get_option("scan8_used")) == 3
     with pytest.raises(nat.RqError):
         idx.set_option("thr_mult8", 0.5)
     with pytest.raises(nat.RqError):
         idx.set_option("scan8", 3)
+    with pytest.raises(nat.RqError):
+        idx.set_option("scan8_split", 2)
     idx.close()
     small = nat.NativeIndex(768, 0)
     xs = orc.synthetic_corpus(50_000, 768, seed=3)
@@ -1399,6 +1405,7 @@ def test_int8_scan_bin_maxima_within_its_measured_bound():
     idx = nat.NativeIndex(768, 0)
     idx.add_f16(x16)
     idx.set_option("scan8", 2)
+    idx.set_option("scan8_split", 0)                                  # one int8 image per query
     worst = _pooled_error(idx, x16, q, range(B))
     assert int(idx.get_option("scan8_used")) == 1
     e_rows = idx.get_option("scan8_row_err")
@@ -1408,6 +1415,12 @@ def test_int8_scan_bin_maxima_within_its_measured_bound():
     bound = float(e_q.max() + (1 + e_q.max()) * e_rows + 2e-5)
     assert worst <= bound, (worst, bound)
     assert worst <= 0.3 * bound, f"observed error {worst} against a bound of {bound}: the int8 threshold assumes a wide margin"
+    # split queries (value + residual image): the query's share of the bound all but vanishes, and so does its share of the error
+    idx.set_option("scan8_split", 1)
+    worst_split = _pooled_error(idx, x16, q, range(B))
+    assert worst_split <= float(e_rows * 1.001 + 1e-4), (worst_split, e_rows)
+    assert worst_split < worst
+    idx.set_option("scan8_split", -1)
     # the library's own view of the rows' error agrees with numpy's
     x = x16.astype(np.float64)
     sr = np.abs(x).max(axis=1, keepdims=True) / 127.0

@@ -28,6 +28,8 @@ def build(n, mode, seed=7):
 for n in (1_000_000, 125_000):
     for mode in ("gaussian", "centroids", "documents"):
         idx, cent, docs = build(n, mode)
+        for opt in filter(None, os.environ.get("RQ_OPTS", "").split(",")):     # e.g. RQ_OPTS=scan8=2,scan8_split=1
+            name, val = opt.split("="); idx.set_option(name, float(val))
         g = torch.Generator(device=dev); g.manual_seed(99)
         for qmode in ("random", "on-topic"):
             if qmode == "random":

@@ -21,8 +21,9 @@ idx.set_option("pipeline", 2)
 res = {}
 for k in (10, 100):
     outs = [(torch.empty((64, k), device=dev), torch.empty((64, k), device=dev, dtype=torch.int64), torch.zeros((64,), device=dev, dtype=torch.int32)) for _ in range(16)]
-    for mode in (0, 1, 0, 1):
-        idx.set_option("scan8", mode)
+    for mode in (0, 2, 3, 0, 2, 3):            # 0 = fp16 scan, 2 = int8 scan, 3 = int8 scan with split queries (two int8 images per query)
+        idx.set_option("scan8", 2 if mode else 0)
+        idx.set_option("scan8_split", 1 if mode == 3 else 0)
         idx.set_option("profile", 0)
         def loop(steps):
             with torch.cuda.stream(st):
@@ -41,5 +42,5 @@ for k in (10, 100):
         res[(k, mode)] = rows
         print(f"k={k:4d} scan8={mode}: {dt * 1e6:7.1f} us/batch  {64 / dt:9.0f} q/s  scan launch {t['scan_ms'] / max(t['scan_launches'], 1) * 1e3:6.1f} us "
               f"({t['scan_bytes'] / max(t['scan_launches'], 1) / 1e6:.0f} MB)  uncertified {unc}  row_err {idx.get_option('scan8_row_err'):.5f}", flush=True)
-    print(f"k={k}: int8 path rows == fp16 path rows: {np.array_equal(res[(k, 0)], res[(k, 1)])}")
+    print(f"k={k}: int8 rows == fp16 rows: {np.array_equal(res[(k, 0)], res[(k, 2)])}, split-query int8 rows == fp16 rows: {np.array_equal(res[(k, 0)], res[(k, 3)])}")
 idx.close()
