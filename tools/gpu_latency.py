@@ -11,11 +11,15 @@ for N in (10_000, 100_000, 1_000_000):
         n = min(125_000, N - c)
         idx.add_f16_device(torch.nn.functional.normalize(torch.randn((n, 768), device=dev), dim=1).half().contiguous(), n)
     rng = np.random.default_rng(3)
-    for B in (1, 64):
+    for B, k in ((1, 10), (1, 50), (64, 10), (64, 100)):      # (1, 50): the reference's evaluation loop, one question, pool of 50
         q = rng.standard_normal((B, 768)).astype(np.float32)
-        for _ in range(20): idx.search(q, 10)
-        t0 = time.perf_counter(); it = 300 if N < 1_000_000 else 100
-        for _ in range(it): idx.search(q, 10)
-        dt = (time.perf_counter() - t0) / it
-        print(f"N={N:8d} B={B:2d}: {dt*1e6:8.1f} us per call  ({B/dt:9.0f} queries/s)", flush=True)
+        line = f"N={N:8d} B={B:2d} k={k:3d}:"
+        for scan8 in (1, 0):                                  # library default (int8 image from 200 k rows) / fp16 scan
+            idx.set_option("scan8", scan8)
+            for _ in range(20): idx.search(q, k)
+            t0 = time.perf_counter(); it = 300 if N < 1_000_000 else 100
+            for _ in range(it): idx.search(q, k)
+            dt = (time.perf_counter() - t0) / it
+            line += f"  {'default' if scan8 else 'fp16 scan'} {dt*1e6:7.1f} us per call ({B/dt:8.0f} queries/s)"
+        print(line, flush=True)
     idx.close()
