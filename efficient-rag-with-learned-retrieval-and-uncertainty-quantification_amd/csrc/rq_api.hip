@@ -426,7 +426,12 @@ static int ensure_x8(rq_index* idx, hipStream_t s) {
         if (e == hipSuccess) e = hipMalloc((void**)&idx->scale8_cos, (size_t)idx->cap * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void**)&idx->scale8_ip, (size_t)idx->cap * sizeof(float));
         if (e == hipSuccess && !idx->d_stat8) e = hipMalloc((void**)&idx->d_stat8, sizeof(unsigned long long));
-        if (e != hipSuccess) { drop_x8(idx); return set_err(RQ_ENOMEM, "hipMalloc of the int8 image of %lld rows failed: %s", (long long)idx->cap, hipGetErrorString(e)); }
+        if (e != hipSuccess) {   // no room for the image (+50 % of the shard): not an error, the fp16 rows remain the scan operand
+            drop_x8(idx);
+            (void)hipGetLastError();
+            idx->scan8_level[0] = idx->scan8_level[1] = 2;
+            return RQ_OK;
+        }
         HIPCHK(hipMemsetAsync(idx->x8, 0, (size_t)idx->cap * RQ_DPAD, s));
         HIPCHK(hipMemsetAsync(idx->scale8_cos, 0xff, (size_t)idx->cap * sizeof(float), s));   // pad rows: NaN (see grow)
         HIPCHK(hipMemsetAsync(idx->scale8_ip, 0xff, (size_t)idx->cap * sizeof(float), s));
@@ -537,7 +542,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     if (allow8 && idx->scan8 && idx->scan8_level[kclass] < 2 && nb >= 0 && 2 * (int64_t)nb < nbins && B <= 64 && !force_generic && idx->fast_tail &&
         k <= RQ_FAST_MAX_K && (idx->scan8 == 2 || (idx->n >= RQ_SCAN8_MIN_ROWS && k <= RQ_SCAN8_AUTO_MAX_K))) {
         if (int r = ensure_x8(idx, s)) return r;
-        use8 = idx->max_e8 <= RQ_SCAN8_MAX_ROW_ERR;
+        use8 = idx->x8 && idx->x8_valid == idx->n && idx->max_e8 <= RQ_SCAN8_MAX_ROW_ERR;
     }
     // Queries as ONE int8 image or as TWO (value + residual: the query's share of the bound vanishes, every corpus fragment
     // feeds two MFMAs).  Measured at 1M rows, fused loop: k = 10  132 us per batch with one image, 143-146 with two (the
