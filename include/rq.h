@@ -130,7 +130,7 @@ int rq_merge_keys_device(const uint64_t* d_keys_in, int n_per_query, int B, int 
  * "use_hint" (0: rq_search_hint_next_device is ignored),
  * "scan8" (calls of <= 64 queries may scan an int8 image of the shard instead of its fp16 rows -- half the bytes per pass;
  *   candidates are still re-scored from the fp16 rows in fp64, so results do not change: 0 = never, 1 = for k <= 128 on shards of
- *   200 000 rows and more (default), 2 = always.  The image (+768 B per row) is built by the first search that wants it; a shard whose
+ *   200 000 rows and more (default), 2 = always.  The image (+768 B per row) is built by the first search that wants it (no room for it: the fp16 rows stay the operand); a shard whose
  *   worst row quantises with more than 3 % relative error keeps the fp16 scan),
  * "scan8_split" (-1 = default: the queries reach the int8 scan as one int8 image for k <= 32 and as two -- value and residual,
  *   twice the matrix-core work, a third of the candidate rows -- for larger k; 0 / 1: one / two images for every k),
