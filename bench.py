@@ -14,6 +14,12 @@ GATHER_EVERY batches and merged on the GPU.  Total work is fixed as N grows => "
 Rank 0 prints ONE JSON line.  Extra objects: "roofline" (scan kernel: algorithmic bytes / HIP-event
 duration measured here, over the timed region) and, at N = 1, "cpu_baseline" (oracle port, fp32
 OpenBLAS brute force on this box's host cores, bounded sample).
+
+--scan auto (default) leaves the choice of the scan's corpus operand to the library: shards of 200 000 rows and more are scanned
+through their int8 image (768 B per row; every returned row is still re-scored in fp64 from the fp16 rows and
+certified, and the results of the timed region are checked against the exact fp64 scan and the oracle afterwards); "roofline"
+then counts the bytes of that image, "dtype" says "i8", and "fp16_scan" carries the same loop over the fp16 rows (--scan fp16
+times that as the main figure: SURVEY 8(d)'s 1536 B per row).
 """
 from __future__ import annotations
 
