@@ -207,6 +207,21 @@ class BM25Index:
             hit = cache[tok] = (np.asarray(rows, dtype=np.int64), np.asarray(self._post_tf[tok], dtype=np.float64))
         return hit
 
+    def _token_contribution(self, tok: str, rows: List[int], idf: Dict[str, float], avgdl: float) -> Tuple[np.ndarray, np.ndarray]:
+        """(rows, idf * tf-saturation per row) of one token for the CURRENT corpus: the same expression the per-query loop used
+        to evaluate, kept until the next add (idf and avgdl change with every added document)."""
+        n_docs = len(self.doc_ids)
+        cache = self.__dict__.setdefault("_contrib", {})
+        if cache.get("#docs") != n_docs:
+            cache.clear()
+            cache["#docs"] = n_docs
+        hit = cache.get(tok)
+        if hit is None:
+            r, f = self._np_postings(tok, rows)
+            w = idf.get(tok) or 0
+            hit = cache[tok] = (r, w * (f * (self.k1 + 1) / (f + self.k1 * (1 - self.b + self.b * self._np_doc_len()[r] / avgdl))))
+        return hit
+
     def get_scores(self, tokenized_query: List[str]) -> np.ndarray:
         n_docs = len(self.doc_ids)
         scores = np.zeros(n_docs)
@@ -214,14 +229,12 @@ class BM25Index:
             return scores
         idf = self._ensure_idf()
         avgdl = self._total_len / n_docs
-        doc_len = self._np_doc_len()
         for tok in tokenized_query:
             rows = self._post_rows.get(tok)
             if not rows:
                 continue
-            r, f = self._np_postings(tok, rows)
-            w = idf.get(tok) or 0
-            scores[r] += w * (f * (self.k1 + 1) / (f + self.k1 * (1 - self.b + self.b * doc_len[r] / avgdl)))
+            r, c = self._token_contribution(tok, rows, idf, avgdl)
+            scores[r] += c
         return scores
 
     def search(self, query: str, top_k: int = 10) -> List[Tuple[str, float]]:
@@ -295,6 +308,7 @@ class BM25Index:
         self._post_rows, self._post_tf, self._doc_len, self._total_len = {}, {}, [], 0
         self.__dict__.pop("_post_np", None)              # numpy views of the posting lists (get_scores): rebuilt on demand
         self.__dict__.pop("_doc_len_np", None)
+        self.__dict__.pop("_contrib", None)
         for row, toks in enumerate(self.tokenized_corpus):
             self._index_tokens(row, toks)
         self._snapshot_docs = len(self.doc_ids)
