@@ -307,6 +307,7 @@ extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     else if (s == "epi" || s == "fused_epi") idx->epi = (int)v != 0;   // selection form of the 64-query scan (default variant and fused launch): 1 = positions inside the scores, 0 = compare / select
     else if (s == "profile_legacy") idx->profile_legacy = (int)v != 0;   // time scans with hipEventRecord around the launch (round 1) instead of dispatch-attached events
     else if (s == "scan8") { if (v < 0 || v > 2) return set_err(RQ_EINVAL, "scan8 must be 0, 1 or 2"); idx->scan8 = (int)v; scan8_reset_levels(idx); }   // see run_pipeline
+    else if (s == "wide8") idx->wide8 = (int)v != 0;   // calls of more than 64 queries may use 128-query passes over the int8 image
     else if (s == "scan8_split") { if (v < -1 || v > 1) return set_err(RQ_EINVAL, "scan8_split must be -1, 0 or 1"); idx->scan8_split = (int)v; scan8_reset_levels(idx); }   // see run_pipeline
     else if (s == "thr_mult8") { if (!(v >= 1.05 && v <= 2.25)) return set_err(RQ_EINVAL, "thr_mult8 %g outside 1.05..2.25", v); idx->thr_mult8 = v; }
     else if (s == "tail_local") idx->tail_local = (int)v != 0;   // A/B: 0 = every re-scored row's key goes to the query's global list
@@ -346,6 +347,7 @@ extern "C" double rq_get_option(const rq_index* idx, const char* name) {
     if (s == "scan8") return idx->scan8;
     if (s == "thr_mult8") return idx->thr_mult8;
     if (s == "scan8_split") return idx->scan8_split;
+    if (s == "wide8") return idx->wide8;
     if (s == "scan8_row_err") return idx->x8_valid == idx->n && idx->x8 ? idx->max_e8 : -1.0;   // worst row's relative int8 error (-1: image not built)
     if (s == "scan8_suspended") return (idx->scan8_level[0] == 2 ? 1.0 : 0.0) + (idx->scan8_level[1] == 2 ? 2.0 : 0.0);   // bit 0: k <= 32, bit 1: larger k
     if (s == "scan8_level") return idx->scan8_level[0] + 10.0 * idx->scan8_level[1];   // per class: 0 one image, 1 two images, 2 fp16 scan   // too many repairs behind the int8 scan (rq_search_fixup_device)
@@ -539,7 +541,10 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     // enough.  Its bound does not involve fp16 subnormals (the image is relative to each row's largest element).
     bool use8 = false;
     const int kclass = k <= RQ_SCAN8_SMALL_K ? 0 : 1;
-    if (allow8 && idx->scan8 && idx->scan8_level[kclass] < 2 && nb >= 0 && 2 * (int64_t)nb < nbins && B <= 64 && !force_generic && idx->fast_tail &&
+    // Calls of more than 64 queries: passes of 128 queries over the image (two 16-query groups per wave, rq_scan.hip I8 = 3) while
+    // the class runs with one image per query and "wide8" is on; otherwise the fp16 passes of rq_scan_wide.hip.
+    const bool wide_ok = B <= 64 || (idx->wide8 && idx->wide_batch != 0 && idx->scan8_level[kclass] == 0);
+    if (allow8 && idx->scan8 && idx->scan8_level[kclass] < 2 && nb >= 0 && 2 * (int64_t)nb < nbins && wide_ok && !force_generic && idx->fast_tail &&
         k <= RQ_FAST_MAX_K && (idx->scan8 == 2 || (idx->n >= RQ_SCAN8_MIN_ROWS && k <= RQ_SCAN8_AUTO_MAX_K))) {
         if (int r = ensure_x8(idx, s)) return r;
         use8 = idx->x8 && idx->x8_valid == idx->n && idx->max_e8 <= RQ_SCAN8_MAX_ROW_ERR;
@@ -565,7 +570,8 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
         const int big = wb == 1 ? 256 : (wb == 2 || wb == 3 ? 128 : 64);
         for (int left = B; left > 0;) {
             int qb = 64;
-            if (big >= 256 && left > 128) qb = 256;
+            if (use8 && B > 64) qb = 128;                       // int8 image: passes of 128 queries
+            else if (big >= 256 && left > 128) qb = 256;
             else if (big >= 128 && left > 64) qb = 128;
             if (npass == 1024) return set_err(RQ_EINVAL, "too many passes");
             pass_q[npass++] = qb;
@@ -659,7 +665,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
         pa.q8lo = cx.ring_q8lo[nslot]; pa.qeps8s = cx.ring_qeps8s[nslot];
     }
     // one scan grid for every pass of the call (the tail reads nwg partition maxima per query): the widest pass decides
-    const int wg_cu = qb0 > 64 ? 1 : idx->wg_per_cu;   // every pass of more than 64 queries runs one 512-thread workgroup per CU
+    const int wg_cu = (qb0 > 64 && !use8) ? 1 : idx->wg_per_cu;   // every fp16 pass of more than 64 queries runs one 512-thread workgroup per CU
     const int grid = (int)std::min<int64_t>(std::min<int64_t>(nquads, RQ_WGMAX_STRIDE), (int64_t)idx->cu_count * wg_cu);
     if (!exact) {
         // non-temporal loads only for shards that cannot stay in the 256 MiB Infinity Cache between two scans
@@ -680,8 +686,8 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             a.wgmax = w.wgmax + (size_t)q0 * RQ_WGMAX_STRIDE;
             a.wgmax_stride = RQ_WGMAX_STRIDE;
             if (use8) {
-                a.i8 = split8 ? 2 : 1; a.qlo = q8lo; a.x = idx->x8; a.row_scale = metric == RQ_METRIC_IP ? idx->scale8_ip : idx->scale8_cos;
-                a.qh = (const _Float16*)q8; a.qscale = qscale8;
+                a.i8 = qb == 128 ? 3 : (split8 ? 2 : 1); a.qlo = q8lo; a.x = idx->x8; a.row_scale = metric == RQ_METRIC_IP ? idx->scale8_ip : idx->scale8_cos;
+                a.qh = (const _Float16*)(q8 + (size_t)q0 * RQ_DPAD); a.qscale = qscale8 + q0;
             }
             const bool prof = idx->profile == 1 && idx->ev_used < 16384 && (idx->scan_seq++ % (uint64_t)idx->profile_stride) == 0;
             hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -709,10 +715,10 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
                 none.nbins = nbins; none.m = none.k = 1; none.thr_mult = 2.25f; none.thr_slack = 0.f;
                 HIPCHK(rq_scan_tail_launch(a, none, 0, pa, nt, grid, idx->epi, s, e0, e1));
             } else if (fused) HIPCHK(rq_scan_launch(a, 3, 1, 2, 4, nt, grid, idx->epi, s, e0, e1));
+            else if (use8) HIPCHK(rq_scan_launch(a, 3, 1, 2, 4, nt, grid, 1, s, e0, e1));   // 64 queries, or 128 (a.i8 = 3)
             else if (qb == 256) HIPCHK(rq_scan_wide_launch(a, idx->wide256, 256, nt, grid, s, e0, e1));
             else if (qb == 128 && idx->wide_batch == 2) HIPCHK(rq_scan_launch(a, 3, 4, 1, 8, nt, grid, 0, s, e0, e1));   // round 1's 8-wave pass
             else if (qb == 128) HIPCHK(rq_scan_wide_launch(a, idx->wide128, 128, nt, grid, s, e0, e1));
-            else if (use8) HIPCHK(rq_scan_launch(a, 3, 1, 2, 4, nt, grid, 1, s, e0, e1));
             else HIPCHK(rq_scan_launch(a, idx->ring, idx->prefetch, idx->kstage, 4, nt, grid, idx->epi, s, e0, e1));
             if (fused && pa.nslots) {
                 cx.prepped_q = cx.hint_q; cx.prepped_B = cx.hint_B; cx.prepped_slot = (slot + 1) % 3;

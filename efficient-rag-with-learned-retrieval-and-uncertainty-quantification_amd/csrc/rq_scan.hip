@@ -60,6 +60,9 @@ __device__ __forceinline__ void rq_wait_vmcnt() {
 //     I8 = 2: the queries are TWO int8 images (value and residual, q = s (254 q_hi + q_lo)); every corpus fragment feeds two
 //     MFMAs and the score is (254 sum_hi + sum_lo) * scales: the query's share of the error bound drops from ~0.008 to ~3e-5
 //     for twice the (idle) matrix-core work and no extra bytes.
+//     I8 = 3: 128 queries per pass -- a wave keeps TWO groups of 16 queries (one int8 image each: 2 x 48 VGPRs, where the fp16
+//     form would need 2 x 96) and every corpus fragment feeds one MFMA per group; records of 128 queries are parked in LDS
+//     (68.5 KB per workgroup: two per CU, so this form is not fused with a tail).
 template <int S, bool NT, int PF, int KS, int QW, int EPI = 0, int I8 = 0>
 __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, const int G) {
     static_assert(S >= 2 && S <= 8, "ring depth");
@@ -76,6 +79,7 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
     constexpr int NSTQ = 4 * KL;                   // stages per quad
     constexpr int VM_KEEP = DPW * (S - 2);         // DMA ops of stages st+1 .. st+S-2 may stay in flight
     constexpr unsigned AUX = NT ? 2u : 0u;
+    constexpr int QG = I8 == 3 ? 2 : 1;            // 16-query groups per wave
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -107,7 +111,7 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
     const char* xb = (const char*)a.x;
     char* norm_lds = rq_smem + S * STAGE_BYTES;                 // [2 parities][64 row scales], shared by the waves
     constexpr int SQ = rq_stage_quads(QW);                      // records per query parked in LDS before they are written out
-    uint2* const stg = (uint2*)(norm_lds + 512);                // [16 * QW queries][SQ] finished records
+    uint2* const stg = (uint2*)(norm_lds + 512);                // [16 * QW * QG queries][SQ] finished records
 
     auto issue = [&](int st, int slot) {
         const int lq = st / NSTQ, t = (st / KL) & 3, kh = st % KL;
@@ -131,21 +135,23 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
     int cslot = 0;   // slot of the stage being consumed
     const float NEG_INF = -__builtin_huge_valf();
     float wmax = NEG_INF;   // largest approximate score this lane has produced (feeds the tail's threshold)
+    float wmax1 = NEG_INF;  // I8 = 3: the same for the second query group
 
     // ---- query fragments: B[k = 8*kg + j][col = r16] of k-step s == qh[16*wave + r16][32*s + 8*kg + j]
     //      (unit-norm fp16 queries written by rq_prep_queries_kernel); loaded while the first stages are in flight
     //      int8: B[k = 16*kg + j][col = r16] of k-step s == q8[16*wave + r16][64*s + 16*kg + j], 12 fragments
     constexpr int NQF = I8 ? 12 : 24;
     rq_half8 qf[NQF];   // (int8: the same 16 bytes per fragment, reinterpreted at the MFMA)
-    rq_half8 ql[I8 == 2 ? 12 : 1];   // I8 = 2: fragments of the residual image
+    rq_half8 ql[I8 >= 2 ? 12 : 1];   // I8 = 2: fragments of the residual image; I8 = 3: of the wave's second query group
     {
-        const rq_half8* qsrc = (const rq_half8*)((const char*)a.qh + (size_t)(16 * wave + r16) * ROWB + 16 * kg);
+        const rq_half8* qsrc = (const rq_half8*)((const char*)a.qh + (size_t)(16 * QG * wave + r16) * ROWB + 16 * kg);
 #pragma unroll
         for (int s = 0; s < NQF; ++s) qf[s] = qsrc[4 * s];
 #pragma unroll
         for (int s = 0; s < NQF; ++s) asm volatile("" : "+v"(qf[s]));   // ordinary loads retired before the main loop
-        if constexpr (I8 == 2) {
-            const rq_half8* lsrc = (const rq_half8*)((const char*)a.qlo + (size_t)(16 * wave + r16) * ROWB + 16 * kg);
+        if constexpr (I8 >= 2) {
+            const rq_half8* lsrc = I8 == 2 ? (const rq_half8*)((const char*)a.qlo + (size_t)(16 * wave + r16) * ROWB + 16 * kg)
+                                           : (const rq_half8*)((const char*)a.qh + (size_t)(16 * QG * wave + 16 + r16) * ROWB + 16 * kg);
 #pragma unroll
             for (int s = 0; s < 12; ++s) ql[s] = lsrc[4 * s];
 #pragma unroll
@@ -153,8 +159,10 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
         }
     }
     float qsc = 1.f;    // int8: s_q / |q| of this lane's query (rq_prep_body), applied once per quad
-    if (I8) qsc = a.qscale[16 * wave + r16];
+    float qsc1 = 1.f;   // I8 = 3: scale of the second group's query
+    if (I8) qsc = a.qscale[16 * QG * wave + r16];
     if (I8 == 2) qsc *= (1.f / 254.f);
+    if (I8 == 3) qsc1 = a.qscale[16 * QG * wave + 16 + r16];
 
     // Finished records wait in LDS and leave in ONE burst per SQ quads (normally once, at the end of the
     // workgroup's range).  Stores inside the streaming loop are what this kernel is sensitive to: every store
@@ -167,14 +175,15 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
         // each wave writes the rows of its own 16 queries: 64 / SQ queries x SQ records (runs of 8 SQ bytes) per instruction
         constexpr int QPI = 64 / SQ;
 #pragma unroll 1
-        for (int i = 0; i < 16 / QPI; ++i) {
-            const int ql = 16 * wave + QPI * i + lane / SQ, j = lane & (SQ - 1);
-            if (j < count && ql < a.nq_valid) a.bins[(int64_t)ql * a.bins_stride + quad0 + j] = stg[ql * SQ + j];
+        for (int i = 0; i < 16 * QG / QPI; ++i) {
+            const int qi = 16 * QG * wave + QPI * i + lane / SQ, j = lane & (SQ - 1);
+            if (j < count && qi < a.nq_valid) a.bins[(int64_t)qi * a.bins_stride + quad0 + j] = stg[qi * SQ + j];
         }
     };
     for (int lq = 0; lq < nloc; ++lq) {
         const int quad = q_lo + lq;
         float m1 = NEG_INF, m2 = NEG_INF, m3 = NEG_INF;   // the three largest approximate scores of the lane's 16 rows
+        float n1 = NEG_INF, n2 = NEG_INF, n3 = NEG_INF;   // I8 = 3: the same for the second query group
         uint32_t ap = 0;                                  // rows (0..63) of the largest [7:0] and second largest [15:8]
         const char* nrow = norm_lds + ((lq & 1) << 8) + kg * 16;
 
@@ -200,7 +209,7 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
                     for (int s = 0; s < PF; ++s) {
                         if constexpr (I8 != 0) {
                             iacc = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(rq_int4, av[s]), __builtin_bit_cast(rq_int4, qf[g + s]), iacc, 0, 0, 0);
-                            if constexpr (I8 == 2) lacc = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(rq_int4, av[s]), __builtin_bit_cast(rq_int4, ql[g + s]), lacc, 0, 0, 0);
+                            if constexpr (I8 >= 2) lacc = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(rq_int4, av[s]), __builtin_bit_cast(rq_int4, ql[g + s]), lacc, 0, 0, 0);
                         } else acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[s], qf[kh * MF + g + s], acc, 0, 0, 0);
                     }
                 }
@@ -215,6 +224,10 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
             if (EPI == 1) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) rq_insert3(m1, m2, m3, rq_pos_score(acc[i] * nv[i], (uint32_t)(t * 16 + i)));
+                if constexpr (I8 == 3) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) rq_insert3(n1, n2, n3, rq_pos_score((float)lacc[i] * nv[i], (uint32_t)(t * 16 + i)));
+                }
             } else
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -231,21 +244,24 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
             }
         }
         if (EPI == 1) {
-            if constexpr (I8 != 0) {   // the query's scale (positive: order unchanged); the positions ride through it
-                m1 = rq_scale_pos(m1, qsc); m2 = rq_scale_pos(m2, qsc); m3 = rq_scale_pos(m3, qsc);
-            }
-            // positions become complete (row group of the lane); the four lanes that share the query insert each other's triples
-            const uint32_t kgb = (uint32_t)kg << 2;
-            m1 = __uint_as_float(__float_as_uint(m1) | kgb); m2 = __uint_as_float(__float_as_uint(m2) | kgb); m3 = __uint_as_float(__float_as_uint(m3) | kgb);
+            // per query group: the query's scale (int8; positive, so the order is unchanged and the positions ride through it), the
+            // lane's row group into the positions, then the four lanes that share the query insert each other's triples
+            auto finish = [&](float x1, float x2, float x3, const float qs, float& wm, const int ql) {
+                if constexpr (I8 != 0) { x1 = rq_scale_pos(x1, qs); x2 = rq_scale_pos(x2, qs); x3 = rq_scale_pos(x3, qs); }
+                const uint32_t kgb = (uint32_t)kg << 2;
+                x1 = __uint_as_float(__float_as_uint(x1) | kgb); x2 = __uint_as_float(__float_as_uint(x2) | kgb); x3 = __uint_as_float(__float_as_uint(x3) | kgb);
 #pragma unroll
-            for (int off = 16; off <= 32; off <<= 1) {
-                const float o1 = __shfl_xor(m1, off, 64), o2 = __shfl_xor(m2, off, 64), o3 = __shfl_xor(m3, off, 64);
-                rq_insert3(m1, m2, m3, o1);
-                rq_insert3(m1, m2, m3, o2);
-                rq_insert3(m1, m2, m3, o3);
-            }
-            asm("v_max_f32 %0, %1, %2" : "=v"(wmax) : "v"(wmax), "v"(m1));
-            if (kg == 0) stg[(16 * wave + r16) * SQ + (lq & (SQ - 1))] = rq_record_from_triple(m1, m2, m3);
+                for (int off = 16; off <= 32; off <<= 1) {
+                    const float o1 = __shfl_xor(x1, off, 64), o2 = __shfl_xor(x2, off, 64), o3 = __shfl_xor(x3, off, 64);
+                    rq_insert3(x1, x2, x3, o1);
+                    rq_insert3(x1, x2, x3, o2);
+                    rq_insert3(x1, x2, x3, o3);
+                }
+                asm("v_max_f32 %0, %1, %2" : "=v"(wm) : "v"(wm), "v"(x1));
+                if (kg == 0) stg[ql * SQ + (lq & (SQ - 1))] = rq_record_from_triple(x1, x2, x3);
+            };
+            finish(m1, m2, m3, qsc, wmax, 16 * QG * wave + r16);
+            if constexpr (I8 == 3) finish(n1, n2, n3, qsc1, wmax1, 16 * QG * wave + 16 + r16);
         } else {
         // merge the four lane groups that share this query (lanes r16, r16+16, r16+32, r16+48): all end up equal
         ap = (ap & 0xffffu) + (uint32_t)(4 * kg) * 0x0101u;
@@ -278,15 +294,21 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
     // per-workgroup maximum of every query: wgmax[query][workgroup]
     wmax = fmaxf(wmax, __shfl_xor(wmax, 16, 64));
     wmax = fmaxf(wmax, __shfl_xor(wmax, 32, 64));
-    if (kg == 0 && 16 * wave + r16 < a.nq_valid) a.wgmax[(int64_t)(16 * wave + r16) * a.wgmax_stride + b] = wmax;
+    if (kg == 0 && 16 * QG * wave + r16 < a.nq_valid) a.wgmax[(int64_t)(16 * QG * wave + r16) * a.wgmax_stride + b] = wmax;
+    if constexpr (I8 == 3) {
+        wmax1 = fmaxf(wmax1, __shfl_xor(wmax1, 16, 64));
+        wmax1 = fmaxf(wmax1, __shfl_xor(wmax1, 32, 64));
+        if (kg == 0 && 16 * QG * wave + 16 + r16 < a.nq_valid) a.wgmax[(int64_t)(16 * QG * wave + 16 + r16) * a.wgmax_stride + b] = wmax1;
+    }
 }
 
 // ring + [2 parities][64 row scales] + record staging [16 * QW queries][rq_stage_quads(QW)]
-static constexpr size_t rq_scan_lds_bytes(int S, int KS, int QW) {
-    return (size_t)S * (24576 / KS) + 512 + (size_t)16 * QW * rq_stage_quads(QW) * 8;
+static constexpr size_t rq_scan_lds_bytes(int S, int KS, int QW, int QG = 1) {
+    return (size_t)S * (24576 / KS) + 512 + (size_t)16 * QW * QG * rq_stage_quads(QW) * 8;
 }
 
-// EPI of the kernels: 0 / 1 = selection form of the fp16 scan, 2 = the int8 scan (selection form 1), 3 = int8 with split queries
+// EPI of the kernels: 0 / 1 = selection form of the fp16 scan, 2 = the int8 scan (selection form 1), 3 = int8 with split queries,
+// 4 = int8 with two query groups per wave (128 queries per pass)
 template <int S, bool NT, int PF, int OCC, int KS, int QW, int EPI>
 __global__ __launch_bounds__(64 * QW, OCC) void rq_scan_kernel(RqScanArgs a) {
     rq_scan_body<S, NT, PF, KS, QW, (EPI >= 2 ? 1 : EPI), (EPI >= 2 ? EPI - 1 : 0)>(a, (int)blockIdx.x, (int)gridDim.x);
@@ -325,7 +347,7 @@ __global__ __launch_bounds__(256, 3) void rq_scan_tail_kernel(RqScanArgs sa, RqT
 
 template <int S, bool NT, int PF, int OCC, int KS, int QW, int EPI>
 static hipError_t rq_scan_launch_t(const RqScanArgs& a, int grid, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
-    const size_t lds = rq_scan_lds_bytes(S, KS, QW);
+    const size_t lds = rq_scan_lds_bytes(S, KS, QW, EPI == 4 ? 2 : 1);
     static unsigned long long attr_done = 0;   // one bit per device
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -352,6 +374,7 @@ static hipError_t rq_scan_launch_r(const RqScanArgs& a, bool nt, int grid, hipSt
 // epi = 1 (selection with positions inside the scores) exists for the default variant (ring 3, prefetch 1, half-row stages, 4 waves)
 hipError_t rq_scan_launch(const RqScanArgs& a, int S, int pf, int ks, int qw, bool nt, int grid, int epi, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
     if (grid <= 0) return hipErrorInvalidValue;
+    if (a.i8 == 3) return (S == 3 && pf == 1 && ks == 2 && qw == 4) ? rq_scan_launch_r<3, 1, 2, 2, 4, 4>(a, nt, grid, stream, e0, e1) : hipErrorInvalidValue;
     if (a.i8 == 2) return (S == 3 && pf == 1 && ks == 2 && qw == 4) ? rq_scan_launch_r<3, 1, 3, 2, 4, 3>(a, nt, grid, stream, e0, e1) : hipErrorInvalidValue;
     if (a.i8) return (S == 3 && pf == 1 && ks == 2 && qw == 4) ? rq_scan_launch_r<3, 1, 3, 2, 4, 2>(a, nt, grid, stream, e0, e1) : hipErrorInvalidValue;
     if (epi && S == 3 && pf == 1 && ks == 2 && qw == 4) return rq_scan_launch_r<3, 1, 3, 2, 4, 1>(a, nt, grid, stream, e0, e1);
@@ -412,6 +435,7 @@ static hipError_t rq_scan_tail_launch_e(const RqScanArgs& sa, const RqTailArgs& 
 hipError_t rq_scan_tail_launch(const RqScanArgs& sa, const RqTailArgs& ta, int tail_B, const RqPrepArgs& pa, bool nt, int scan_grid, int epi, hipStream_t stream,
                                hipEvent_t e0, hipEvent_t e1) {
     if (pa.nslots < 0 || pa.nslots > 64) return hipErrorInvalidValue;
+    if (sa.i8 == 3) return hipErrorInvalidValue;   // the 128-query form is not fused with a tail (LDS)
     if (sa.i8 == 2) return rq_scan_tail_launch_e<3>(sa, ta, tail_B, pa, nt, scan_grid, stream, e0, e1);
     if (sa.i8) return rq_scan_tail_launch_e<2>(sa, ta, tail_B, pa, nt, scan_grid, stream, e0, e1);
     return epi ? rq_scan_tail_launch_e<1>(sa, ta, tail_B, pa, nt, scan_grid, stream, e0, e1)

@@ -128,12 +128,14 @@ int rq_merge_keys_device(const uint64_t* d_keys_in, int n_per_query, int B, int 
  * 256 / 128 / 64, 3 = 128 / 64, 2 = round 1's 8-wave 128-query pass), "wide128" / "wide256" (variant of csrc/rq_scan_wide.hip),
  * "epi" (selection form of the 64-query scan: 1 = row positions inside the scores, 0 = compare / select),
  * "use_hint" (0: rq_search_hint_next_device is ignored),
- * "scan8" (calls of <= 64 queries may scan an int8 image of the shard instead of its fp16 rows -- half the bytes per pass;
+ * "scan8" (searches may scan an int8 image of the shard instead of its fp16 rows -- half the bytes per pass;
  *   candidates are still re-scored from the fp16 rows in fp64, so results do not change: 0 = never, 1 = for k <= 128 on shards of
  *   200 000 rows and more (default), 2 = always.  The image (+768 B per row) is built by the first search that wants it (no room for it: the fp16 rows stay the operand); a shard whose
  *   worst row quantises with more than 3 % relative error keeps the fp16 scan),
  * "scan8_split" (-1 = default: the queries reach the int8 scan as one int8 image for k <= 32 and as two -- value and residual,
  *   twice the matrix-core work, a third of the candidate rows -- for larger k; 0 / 1: one / two images for every k),
+ * "wide8" (default 1: calls of more than 64 queries whose k class runs with one int8 image use 128-query passes over the image;
+ *   0: the fp16 passes of "wide_batch"),
  * "thr_mult8" (1.05 .. 2.25, default 1.25: candidate threshold of the int8 scan, T = P - bound - (thr_mult8 - 1) * max(bound,
  *   typical one-image bound); 2.25 certifies by construction, smaller values re-score fewer rows and leave the rare query
  *   whose errors add up to the repair path of rq_search_fixup_device.  When more than 1 in 16 checked queries of a class of

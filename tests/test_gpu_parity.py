@@ -1512,3 +1512,33 @@ def test_fused_nomic_bert_forward_matches_the_stock_module():
     la, lb = fused.embed(long_texts), stock.embed(long_texts)
     lcos = (la * lb).sum(1) / (np.linalg.norm(la, axis=1) * np.linalg.norm(lb, axis=1))
     assert lcos.min() >= 0.9999, lcos.min()
+
+
+def test_int8_wide_passes_match_oracle():
+    """Calls of more than 64 queries with k <= 32 on a shard the int8 scan accepts: passes of 128 queries over the image (two
+    16-query groups per wave, csrc/rq_scan.hip I8 = 3).  B = 65 .. 333 (ragged last pass), cosine and inner product, a zero
+    query, duplicates (ties by row id), rows appended in between; option wide8 = 0 restores the fp16 passes; rows identical to
+    the oracle, |score difference| <= 1e-6."""
+    x16 = orc.synthetic_corpus(60_000, 768, seed=81)
+    x16[200:260] = x16[7]
+    idx = nat.NativeIndex(768, 0)
+    idx.add_f16(x16[:50_011])
+    idx.set_option("scan8", 2)
+    n = 50_011
+    for B, k in ((65, 10), (128, 10), (200, 32), (333, 5)):
+        q = orc.synthetic_queries(B, 768, seed=B + k)
+        q[1] = 0
+        q[2] = x16[7].astype(np.float32)
+        before = int(idx.get_option("scan8_used"))
+        _check(idx, x16[:n], q, k)
+        assert int(idx.get_option("scan8_used")) == before + 1, (B, k)
+        if B == 128:
+            idx.add_f16(x16[50_011:]); n = 60_000                  # the image follows the append
+    _check(idx, x16, 2.5 * orc.synthetic_queries(130, 768, seed=3), 10, nat.METRIC_IP)
+    before = int(idx.get_option("scan8_used"))
+    _check(idx, x16, orc.synthetic_queries(130, 768, seed=4), 100)  # k > 32: two-image class -> the fp16 wide passes
+    idx.set_option("wide8", 0)
+    _check(idx, x16, orc.synthetic_queries(130, 768, seed=5), 10)   # switched off -> the fp16 wide passes
+    assert int(idx.get_option("scan8_used")) == before
+    assert idx.timing()["exact_scans"] <= 2                          # (the zero queries may take the exact route)
+    idx.close()
