@@ -532,13 +532,11 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     const int binrows = RQ_BIN_ROWS;
     const int nquads = (int)((idx->n + 63) / 64);
     const int64_t nbins = nquads;   // bin = quad
-    // tiny shards (fewer than two bins per wanted bin): the approximate pass cannot narrow anything down
-    // ... and shards whose rows keep so much of their norm in fp16-subnormal elements that the scan's scores say nothing
-    // int8 scan ("scan8": 0 = never, 1 = k <= RQ_SCAN8_AUTO_MAX_K on shards of RQ_SCAN8_MIN_ROWS rows and more -- below that the scan is too short for
-    // the saving to outweigh the larger candidate sets the looser bound brings (fused two-stream loop, us per batch int8 / fp16:
-    // 250k rows 35.0 / 59.8, 125k rows 25.0 / 29.0 on Gaussian rows, but 144 / 101 at 125k rows of a document-structured
-    // corpus, profiles/r02_clustered_int8.txt) --, 2 = always): one pass of <= 64 queries over the int8 image of the shard, when its worst row quantises well
-    // enough.  Its bound does not involve fp16 subnormals (the image is relative to each row's largest element).
+    // int8 scan ("scan8": 0 = never; 1 = k <= RQ_SCAN8_AUTO_MAX_K on shards of RQ_SCAN8_MIN_ROWS rows and more; 2 = always): the scan
+    // reads the int8 image of the shard when its worst row quantises well enough.  The size rule: on Gaussian rows the image
+    // pays down to 125k rows (fused two-stream loop, us per batch int8 / fp16: 250k rows 35.0 / 59.8, 125k rows 25.0 / 29.0),
+    // but a 125k-row document-structured shard takes 144 us against 101 (profiles/r02_clustered_int8.txt).  Its bound does not
+    // involve fp16 subnormals (the image is relative to each row's largest element), so it is decided BEFORE `exact` below.
     bool use8 = false;
     const int kclass = k <= RQ_SCAN8_SMALL_K ? 0 : 1;
     // Calls of more than 64 queries: passes of 128 queries over the image (two 16-query groups per wave, rq_scan.hip I8 = 3) while
@@ -557,6 +555,8 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     // one image -> two images -> fp16 scan (clustered corpus + random queries at k = 10: one image 19 of 64 queries repaired,
     // two images none, 245 us per batch against 275 with the fp16 scan).
     const bool split8 = use8 && idx->scan8_level[kclass] == 1;
+    // tiny shards (fewer than two bins per wanted bin): the approximate pass cannot narrow anything down
+    // ... and shards whose rows keep so much of their norm in fp16-subnormal elements that the fp16 scan's scores say nothing
     const bool exact = nb < 0 || 2 * (int64_t)nb >= nbins || (!use8 && idx->eps < 0 && scan_eps(idx, metric) > RQ_EPS_USELESS);
     if (exact) nb = (int)std::min<int64_t>(nbins, INT32_MAX / 64);
     if (!exact && nb > RQ_NB_MAX) return set_err(RQ_EINVAL, "nb %d too large", nb);
