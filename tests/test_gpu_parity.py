@@ -856,6 +856,9 @@ def test_long_structured_sweep():
         mode = int(rng.choice([0, 1, 2]))
         idx.set_option("epi", int(rng.integers(0, 2)))
         idx.set_option("wide_batch", int(rng.choice([1, 1, 3, 0])))
+        idx.set_option("scan8", int(rng.choice([0, 1, 2, 2, 2])))        # the int8 image: never / size rule / always,
+        idx.set_option("scan8_split", int(rng.choice([-1, -1, 0, 1])))    #   one or two images per query, 128-query passes
+        idx.set_option("wide8", int(rng.choice([1, 1, 0])))
         try:
             if mode == 0:
                 _check(idx, x16, q, k, metric)
