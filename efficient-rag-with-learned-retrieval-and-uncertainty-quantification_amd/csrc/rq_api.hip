@@ -535,7 +535,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     // int8 scan ("scan8": 0 = never; 1 = k <= RQ_SCAN8_AUTO_MAX_K on shards of RQ_SCAN8_MIN_ROWS rows and more; 2 = always): the scan
     // reads the int8 image of the shard when its worst row quantises well enough.  The size rule: on Gaussian rows the image
     // pays down to 125k rows (fused two-stream loop, us per batch int8 / fp16: 250k rows 35.0 / 59.8, 125k rows 25.0 / 29.0),
-    // but a 125k-row document-structured shard takes 144 us against 101 (profiles/r02_clustered_int8.txt).  Its bound does not
+    // but a 125k-row document-structured shard takes 64 us against 34 in the same loop (profiles/r02_shard_shapes.txt).  Its bound does not
     // involve fp16 subnormals (the image is relative to each row's largest element), so it is decided BEFORE `exact` below.
     bool use8 = false;
     const int kclass = k <= RQ_SCAN8_SMALL_K ? 0 : 1;
