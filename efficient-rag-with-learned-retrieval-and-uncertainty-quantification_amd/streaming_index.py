@@ -394,15 +394,18 @@ class DenseIndex:
 
     Signature and defaults follow reference :236-243.  `chroma_host` / `chroma_port` are accepted for
     call compatibility and ignored (there is no service).  Keyword-only extras: `embedder`, `device`,
-    `metric`.  Construction raises when the GPU backend is unavailable, as the reference raises
+    `metric`, `backend_options`.  Construction raises when the GPU backend is unavailable, as the reference raises
     ImportError without chromadb (:248-249).
     """
 
     def __init__(self, collection_name: str = "rag_documents", persist_directory: str = "./data/chroma_db",
                  embedding_model: str = "nomic-embed-text", chroma_host: Optional[str] = None, chroma_port: int = 8000,
                  *, embedder=None, device: int = 0, devices: Optional[Sequence[int]] = None, metric: str = "cosine",
-                 load_persisted: bool = True, auto_persist: bool = True):
+                 load_persisted: bool = True, auto_persist: bool = True, backend_options: Optional[Dict[str, float]] = None):
         self.collection_name = collection_name
+        # options of the C library (include/rq.h rq_set_option), applied when the index is created or loaded -- e.g.
+        # {"scan8": 0} keeps the fp16 rows as the only copy of the corpus in HBM (no int8 image for the scan)
+        self.backend_options = dict(backend_options or {})
         self.persist_directory = persist_directory
         self.embedding_model = embedding_model
         if chroma_host:
@@ -461,8 +464,13 @@ class DenseIndex:
                 self._index = MultiDeviceIndex(self.dim, self.devices)
             else:
                 self._index = _native.NativeIndex(self.dim, self.devices[0] if self.devices else self.device)
+            self._apply_backend_options()
         elif dim != self.dim:
             raise ValueError(f"embedding dimension {dim} does not match the index ({self.dim})")
+
+    def _apply_backend_options(self) -> None:
+        for name, value in self.backend_options.items():
+            self._index.set_option(name, float(value))
 
     def add_documents(self, documents: List[Document], batch_size: int = 100) -> int:
         # the reference fetches every stored id per call (:306); a hash table does the same filter
@@ -581,6 +589,7 @@ class DenseIndex:
         if committed is None:
             return
         self._index = _native.NativeIndex.load(str(base), self.device, devices=self.devices)
+        self._apply_backend_options()
         self.dim = self._index.dim
         with open(docs_path) as f:
             for line in f:

@@ -494,8 +494,9 @@ def test_dense_index_and_hybrid_retriever_end_to_end(tmp_path):
     assert len(again) == 500 and again.search(docs[42].text, 1)[0][0] == "p42"
     assert again.search("passage 3 about topic 3", 20) == r.dense_index.search("passage 3 about topic 3", 20)
     again.add_documents([si.Document(id="late", text="a late passage about nothing")])          # appends to the files
-    third = si.DenseIndex(persist_directory=str(tmp_path / "chroma"), embedder=HashEmbedder())
+    third = si.DenseIndex(persist_directory=str(tmp_path / "chroma"), embedder=HashEmbedder(), backend_options={"scan8": 0, "wide_batch": 3})
     assert len(third) == 501 and third.search("a late passage about nothing", 1)[0][0] == "late"
+    assert third._index.get_option("scan8") == 0 and third._index.get_option("wide_batch") == 3      # library options reach a reloaded index
     fresh = si.HybridRetriever(bm25_persist_path=str(tmp_path / "b.pkl"), chroma_persist_path=str(tmp_path / "chroma"), embedder=HashEmbedder())
     assert len(fresh) == 500 and fresh.hybrid_search(docs[42].text, top_k=1)[0].doc_id == "p42"
     # failed embedding -> zero vector -> still answers (reference :281-284)
