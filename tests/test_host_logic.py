@@ -279,3 +279,27 @@ def test_bm25_numpy_posting_views_follow_appends_and_reloads(tmp_path):
     inc.close()
     again = si.BM25Index(persist_path=str(tmp_path / "bm25.pkl"))
     assert [again.search(q, 20) for q in queries] == [fresh.search(q, 20) for q in queries]
+
+
+def test_fused_encoder_accepts_only_the_architecture_it_was_written_for():
+    """embedders.FusedNomicBertForward inspects the module it wraps (no GPU needed for that): the stock NomicBert layout is
+    accepted and its q/k/v and gate/up weights are concatenated; a projection with a bias, another head size or another
+    activation make it decline, and NomicBertEmbedder then keeps the stock forward."""
+    torch = pytest.importorskip("torch")
+    from transformers.models.nomic_bert import NomicBertConfig, NomicBertModel
+    from rag_uq_amd.embedders import FusedNomicBertForward
+    cfg = NomicBertConfig(); cfg.num_hidden_layers = 2
+    model = NomicBertModel(cfg).eval()
+    f = FusedNomicBertForward(model)
+    assert f.ok and len(f.layers) == 2 and f.theta == 1000.0 and f.heads == 12
+    assert tuple(f.layers[0]["wqkv"].shape) == (3 * 768, 768) and tuple(f.layers[0]["wgu"].shape) == (2 * 3072, 768)
+    a = model.layers[0].self_attn
+    assert torch.equal(f.layers[0]["wqkv"][768:1536], a.k_proj.weight)
+    ids = torch.zeros((2, 5), dtype=torch.long); mask = torch.ones((2, 5), dtype=torch.long)
+    assert not f.usable(ids, mask)                                   # CPU tensors / fp32 weights: the stock forward
+    a.q_proj.bias = torch.nn.Parameter(torch.zeros(768))
+    assert not FusedNomicBertForward(model).ok
+    cfg2 = NomicBertConfig(); cfg2.num_hidden_layers = 1; cfg2.hidden_act = "gelu"
+    assert not FusedNomicBertForward(NomicBertModel(cfg2)).ok
+    cfg3 = NomicBertConfig(); cfg3.num_hidden_layers = 1; cfg3.num_attention_heads = 6; cfg3.head_dim = 128
+    assert not FusedNomicBertForward(NomicBertModel(cfg3)).ok
