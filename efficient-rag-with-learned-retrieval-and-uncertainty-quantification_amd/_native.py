@@ -304,3 +304,63 @@ def merge_keys_device(d_keys_in, n_per_query: int, B: int, k: int, d_scores, d_r
     lib = load_library()
     _check(lib.rq_merge_keys_device(_ptr(d_keys_in), int(n_per_query), int(B), int(k), _ptr(d_scores), _ptr(d_rows),
                                     _ptr(d_keys_out), C.c_void_p(stream)), "rq_merge_keys_device")
+
+
+# -- librq_bm25.so (include/rq_bm25.h, csrc/rq_bm25.cpp): batched CPU BM25 for BM25Index.search_batch -- host cores, no GPU code ----------
+BM25_LIB_PATH = _PKG_DIR / "librq_bm25.so"
+_BM25_SIGNATURES = {
+    "rq_bm25_create": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
+    "rq_bm25_destroy": (None, [C.c_void_p]),
+    "rq_bm25_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "rq_bm25_version": (C.c_char_p, []),
+}
+_bm25_lib: Optional[C.CDLL] = None
+
+
+def load_bm25_library() -> C.CDLL:
+    global _bm25_lib
+    if _bm25_lib is None:
+        if not BM25_LIB_PATH.exists():
+            raise RqError(f"{BM25_LIB_PATH} is missing: build it with `make -C {(_PKG_DIR / 'csrc')}`")
+        lib = C.CDLL(str(BM25_LIB_PATH))
+        for name, (res, args) in _BM25_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _bm25_lib = lib
+    return _bm25_lib
+
+
+def bm25_available() -> bool:
+    try:
+        load_bm25_library()
+        return True
+    except (RqError, OSError):
+        return False
+
+
+def bm25_create(indptr: np.ndarray, rows: np.ndarray, contrib: np.ndarray, n_tokens: int, n_docs: int) -> int:
+    """Handle over BORROWED arrays (the caller keeps them alive until bm25_destroy)."""
+    assert indptr.dtype == np.int64 and rows.dtype == np.int32 and contrib.dtype == np.float64
+    assert indptr.flags.c_contiguous and rows.flags.c_contiguous and contrib.flags.c_contiguous and len(indptr) == n_tokens + 1
+    h = load_bm25_library().rq_bm25_create(_ptr(indptr), _ptr(rows), _ptr(contrib), int(n_tokens), int(n_docs))
+    if not h:
+        raise RqError("rq_bm25_create: malformed posting arrays")
+    return h
+
+
+def bm25_destroy(handle: int) -> None:
+    if handle and _bm25_lib is not None:
+        _bm25_lib.rq_bm25_destroy(C.c_void_p(handle))
+
+
+def bm25_topk(handle: int, q_indptr: np.ndarray, q_tokens: np.ndarray, n_queries: int, k: int, n_threads: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+    out_rows = np.empty((n_queries, k), np.int32)
+    out_scores = np.empty((n_queries, k), np.float64)
+    q_indptr = np.ascontiguousarray(q_indptr, np.int64)
+    q_tokens = np.ascontiguousarray(q_tokens, np.int32)
+    rc = load_bm25_library().rq_bm25_topk(C.c_void_p(handle), _ptr(q_indptr), _ptr(q_tokens) if len(q_tokens) else None, int(n_queries), int(k),
+                                          _ptr(out_rows), _ptr(out_scores), int(n_threads))
+    if rc != 0:
+        raise RqError(f"rq_bm25_topk failed (code {rc})")
+    return out_rows, out_scores

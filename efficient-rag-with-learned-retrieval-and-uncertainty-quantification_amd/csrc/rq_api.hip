@@ -180,12 +180,7 @@ extern "C" int rq_index_set_row_offset(rq_index* idx, int64_t off) {
 }
 extern "C" int rq_index_reserve(rq_index* idx, int64_t n_rows) {
     if (!idx || n_rows < 0) return set_err(RQ_EINVAL, "bad reserve");
-    if (!idx->shards.empty()) {
-        const int64_t g = (int64_t)idx->shards.size();
-        for (rq_index* c : idx->shards)
-            if (int r = rq_index_reserve(c, (n_rows + g - 1) / g)) return r;
-        return RQ_OK;
-    }
+    if (!idx->shards.empty()) return rq_multi_reserve(idx, n_rows);
     RQ_ON_DEVICE(idx);
     return grow(idx, n_rows);
 }
@@ -282,6 +277,12 @@ static void scan8_reset_levels(rq_index* idx) {
 extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     if (!idx || !name) return set_err(RQ_EINVAL, "bad option call");
     if (!idx->shards.empty()) {
+        if (std::string(name) == "stripe_rows") {   // multi-device parent: rows per stripe (rq_multi.hip), before the first append only
+            if (idx->n != 0) return set_err(RQ_EINVAL, "stripe_rows can only be set on an empty multi-device index");
+            if (v < 64 || v > (double)(1 << 30) || (int64_t)v % 64 != 0) return set_err(RQ_EINVAL, "stripe_rows must be a multiple of 64 in 64..2^30");
+            idx->stripe = (int64_t)v;
+            return RQ_OK;
+        }
         for (rq_index* c : idx->shards)
             if (int r = rq_set_option(c, name, v)) return r;
         return RQ_OK;
@@ -319,8 +320,9 @@ extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
 extern "C" double rq_get_option(const rq_index* idx, const char* name) {
     if (!idx || !name) return NAN;
     if (!idx->shards.empty()) {   // the statistics are shard maxima, everything else is the same on every child
-        double v = rq_get_option(idx->shards[0], name);
         const std::string o(name);
+        if (o == "stripe_rows") return (double)idx->stripe;
+        double v = rq_get_option(idx->shards[0], name);
         if (o.rfind("max_", 0) == 0 || o.rfind("eps_", 0) == 0 || o == "scan8_row_err" || o == "scan8_suspended")
             for (rq_index* c : idx->shards) v = std::max(v, rq_get_option(c, name));
         if (o == "scan8_used" || o == "hints_used") {   // counters: summed
@@ -494,12 +496,25 @@ static int flush_tails(rq_index* idx, hipStream_t s) {
     return RQ_OK;
 }
 
+// Every tail still waiting for a scan ("pipeline" = 2), of every stream the index remembers.  The callers' stream handles are
+// NOT used for it (a caller may have destroyed a stream it no longer searches on; only rq_stream_release tells us): the device
+// is drained first -- every scan those tails depend on has then finished -- and the tails run on the index's own stream.
 static int flush_all(rq_index* idx) {
-    if (idx->ctx.empty()) return RQ_OK;
+    bool any = false;
+    for (auto& kv : idx->ctx) any = any || kv.second.fused_pending || kv.second.tail_pending[0] || kv.second.tail_pending[1];
+    if (!any) return RQ_OK;
     RQ_ON_DEVICE(idx);
-    for (auto& kv : idx->ctx)
-        if (kv.second.fused_pending)
-            if (int r = flush_tails(idx, kv.first)) return r;
+    HIPCHK(hipDeviceSynchronize());
+    for (auto& kv : idx->ctx) {
+        StreamCtx& c = kv.second;
+        c.hint_q = nullptr;
+        c.tail_pending[0] = c.tail_pending[1] = false;   // (their events have fired: the device is idle)
+        if (!c.fused_pending) continue;
+        c.fused_pending = false;
+        if (int r = poison_cand(idx, c.fused_tail, c.fused_B, idx->own_stream)) return r;
+        HIPCHK(rq_tail_launch(c.fused_tail, c.fused_B, idx->own_stream));
+    }
+    HIPCHK(hipStreamSynchronize(idx->own_stream));
     return RQ_OK;
 }
 
@@ -645,6 +660,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     signed char* const q8lo = fused ? cx.ring_q8lo[slot] : w.q8lo;
     float* const qeps8s = fused ? cx.ring_qeps8s[slot] : w.qeps8s;
     if (use8) idx->scan8_used++;
+    if (may_defer) idx->last_use8 = use8;   // (may_defer: the caller's own search, not a repair pass of rq_search_fixup_device)
     // ... unless the previous launch of this stream has already prepared exactly these queries (rq_search_hint_next_device)
     const bool prepared = fused && cx.prepped_q == d_q && cx.prepped_B == B && cx.prepped_slot == slot;
     cx.prepped_q = nullptr;
@@ -818,7 +834,12 @@ extern "C" int rq_search_hint_next_device(rq_index* idx, const float* d_next_que
     if (!idx) return set_err(RQ_EINVAL, "null index");
     if (!idx->shards.empty()) return set_err(RQ_EUNSUPPORTED, "device-pointer searches on a multi-device index: use rq_search (host buffers), or one index per device");
     if (B < 0 || B > 65535) return set_err(RQ_EINVAL, "B %d outside 0..65535", B);
-    if (idx->ctx.find((hipStream_t)stream) == idx->ctx.end() && idx->ctx.size() >= RQ_MAX_STREAM_CTX) return RQ_OK;   // dropped: advisory
+    // Advisory.  A hint for a stream no search has run on yet only makes a host-side record (no device memory, no device call:
+    // hence no device guard here); the workspace is allocated by the search that follows.  Beyond RQ_MAX_STREAM_CTX remembered
+    // streams the hint is dropped instead (the call then prepares its own queries).  Remembered stream handles are never used
+    // again by the library on its own account (flush_all runs pending tails on the index's own stream), so a record for a stream
+    // the caller destroys later is harmless.
+    if (idx->ctx.find((hipStream_t)stream) == idx->ctx.end() && idx->ctx.size() >= RQ_MAX_STREAM_CTX) return RQ_OK;
     StreamCtx& c = idx->ctx[(hipStream_t)stream];
     const bool usable = d_next_queries && B >= 1 && B <= 64 && idx->use_hint && idx->pipeline == 2;
     c.hint_q = usable ? d_next_queries : nullptr;
@@ -831,6 +852,22 @@ extern "C" int rq_search_flush_device(rq_index* idx, void* stream) {
     if (!idx->shards.empty()) return RQ_OK;
     RQ_ON_DEVICE(idx);
     return flush_tails(idx, (hipStream_t)stream);
+}
+
+// The int8 scan bets that real errors stay well below its worst-case bound (threshold multiplier thr_mult8 < 2) and that few
+// rows sit within that bound of the k-th score.  A shard / query mix on which either fails shows up as repairs: beyond 1 in 16
+// CHECKED queries (windows of 256) the class of k moves one step along one image -> two images -> fp16 scan, until "scan8" /
+// "scan8_split" is set again.  Every checked query counts, the clean ones too (rq_search_end's clean branch reports them: a
+// server answering one query per call must not see only its failures), whatever the size of the call.
+static void scan8_account(rq_index* idx, int k, int checked, int repaired) {
+    if (!idx->last_use8 || !idx->x8 || !idx->scan8) return;
+    const int kclass = k <= RQ_SCAN8_SMALL_K ? 0 : 1;
+    if (idx->scan8_level[kclass] >= 2) return;
+    idx->scan8_checked[kclass] += checked; idx->scan8_repaired[kclass] += repaired;
+    if (idx->scan8_checked[kclass] >= 256) {
+        if (idx->scan8_repaired[kclass] * 16 > idx->scan8_checked[kclass]) idx->scan8_level[kclass]++;
+        idx->scan8_checked[kclass] = idx->scan8_repaired[kclass] = 0;
+    }
 }
 
 extern "C" int rq_search_fixup_device(rq_index* idx, const float* d_queries, int B, int k, int metric, float* d_scores,
@@ -846,18 +883,7 @@ extern "C" int rq_search_fixup_device(rq_index* idx, const float* d_queries, int
     HIPCHK(hipStreamSynchronize(s));
     std::vector<int> bad;
     for (int q = 0; q < B; ++q) if (st[q] != 0) bad.push_back(q);
-    // The int8 scan bets that real errors stay well below its worst-case bound (threshold multiplier thr_mult8 < 2) and that
-    // few rows sit within that bound of the k-th score.  A shard / query mix on which either fails shows up here as repairs:
-    // beyond 1 in 16 checked queries (windows of 256) the class of k moves one step along one image -> two images -> fp16 scan,
-    // until "scan8" / "scan8_split" is set again.
-    const int kclass = k <= RQ_SCAN8_SMALL_K ? 0 : 1;
-    if (idx->x8 && idx->scan8 && idx->scan8_level[kclass] < 2 && B <= 64) {
-        idx->scan8_checked[kclass] += B; idx->scan8_repaired[kclass] += (int64_t)bad.size();
-        if (idx->scan8_checked[kclass] >= 256) {
-            if (idx->scan8_repaired[kclass] * 16 > idx->scan8_checked[kclass]) idx->scan8_level[kclass]++;
-            idx->scan8_checked[kclass] = idx->scan8_repaired[kclass] = 0;
-        }
-    }
+    scan8_account(idx, k, B, (int)bad.size());
     if (bad.empty()) return 0;
     const int repaired = (int)bad.size();
     Workspace& w = idx->ctx[s].w[0];
@@ -874,7 +900,7 @@ extern "C" int rq_search_fixup_device(rq_index* idx, const float* d_queries, int
     // ladder: (queries that came from the int8 scan: the fp16 scan, whose threshold certifies by construction,) 4x wider
     // candidate set, then the full fp64 scan
     const int nb1 = std::min(RQ_NB_MAX, 4 * nb_default(idx, k));
-    const bool from8 = idx->x8 && idx->scan8 && B <= 64;
+    const bool from8 = idx->last_use8 && idx->x8 && idx->scan8;
     for (int level = from8 ? -1 : 0; level < 2 && !bad.empty(); ++level) {
         const int nbq = (int)bad.size();
         for (int i = 0; i < nbq; ++i)
@@ -984,7 +1010,7 @@ int rq_search_end(rq_index* idx, int B, int k, int metric, float* out_scores, in
             if (fr < 0) return fr;
             HIPCHK(hipMemcpyAsync(idx->hs_pin, idx->hs_dev, off_t, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
-        }
+        } else scan8_account(idx, k, B, 0);   // the int8 ladder sees the clean calls too
         std::memcpy(out_rows, idx->hs_pin, off_s);
         std::memcpy(out_scores, idx->hs_pin + off_s, off_t - off_s);
         return RQ_OK;
@@ -1153,6 +1179,10 @@ extern "C" rq_index* rq_load(const char* path, int n_devices, const int* device_
     if (!idx) return nullptr;
     f = fopen(data.c_str(), "rb");
     if (!f) { set_err(RQ_EIO, "cannot read %s", data.c_str()); rq_index_destroy(idx); return nullptr; }
+    if (!idx->shards.empty()) {   // multi-device: stripes no longer than an even share, so that a small collection still uses every device
+        const int64_t g = (int64_t)idx->shards.size(), share = ((rows + g - 1) / g + 63) / 64 * 64;
+        idx->stripe = std::min<int64_t>(idx->stripe, std::max<int64_t>(share, 4096));
+    }
     if (rows > 0 && rq_index_reserve(idx, rows) != RQ_OK) { fclose(f); rq_index_destroy(idx); return nullptr; }
     const int64_t chunk = 65536;
     std::vector<uint16_t> buf((size_t)chunk * dim);

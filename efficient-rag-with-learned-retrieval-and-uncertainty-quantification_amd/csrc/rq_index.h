@@ -120,6 +120,7 @@ struct rq_index {
     int scan8_level[2] = {0, 1};
     int64_t scan8_checked[2] = {0, 0}, scan8_repaired[2] = {0, 0};
     int64_t scan8_used = 0;        // searches that scanned the int8 image
+    bool last_use8 = false;        // the caller's last search scanned the int8 image (what rq_search_fixup_device's repairs are counted against)
     int64_t hints_used = 0;        // rq_search_hint_next_device: searches that skipped their preparation launch
     uint64_t scan_seq = 0;         // scan launches seen while profile = 1 (every profile_stride-th one is timed)
     // options
@@ -136,11 +137,15 @@ struct rq_index {
     void* add_stage = nullptr; size_t add_stage_bytes = 0;   // device staging of host-row appends
     bool hs_small = false;         // which staging path the search in flight uses (search_begin / search_end)
     // Multi-device parent (rq_index_create with n_devices > 1): no device memory of its own, one single-device child per
-    // entry of device_ids.  Every appended block is cut into contiguous pieces, piece j goes to child j, so a child holds
-    // several segments of global ids; seg_local[j] = local start of each segment (+ end sentinel), seg_global[j] = its
-    // global start.  Local order inside a child is monotone in the global id.
+    // entry of device_ids.  Global rows are dealt to the children in stripes of `stripe` rows, round robin (rq_multi.hip):
+    // global row g -> stripe s = g / stripe, child s % G, local row (s / G) * stripe + g % stripe.
     std::vector<rq_index*> shards;
-    std::vector<std::vector<int64_t>> seg_local, seg_global;
+    int64_t stripe = 65536;
+    bool poisoned = false;         // an append failed part-way inside a child: the global <-> local mapping no longer holds
+    std::vector<size_t> m_live;    // search staging of the parent, kept between calls: children that hold rows,
+    std::vector<float> m_scores;   // their k best scores [live child][B][k]
+    std::vector<int64_t> m_rows;   // and local rows
+    int m_B = 0;
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t ev_used = 0;
@@ -188,6 +193,7 @@ RQ_INTERNAL int rq_add_host_common(rq_index* idx, const void* rows, int64_t n_ro
 RQ_INTERNAL int rq_search_begin(rq_index* idx, const float* queries, int B, int k, int metric);      // stage + enqueue, no wait
 RQ_INTERNAL int rq_search_end(rq_index* idx, int B, int k, int metric, float* out_scores, int64_t* out_rows);   // wait, repair, hand over
 RQ_INTERNAL rq_index* rq_multi_create(int dim, int n_devices, const int* device_ids);
+RQ_INTERNAL int rq_multi_reserve(rq_index* idx, int64_t n_rows);
 RQ_INTERNAL int rq_multi_add(rq_index* idx, const void* rows, int64_t n_rows, bool is_f32, int normalize);
 RQ_INTERNAL int rq_multi_get_rows(const rq_index* idx, int64_t row_begin, int64_t n_rows, uint16_t* out);
 RQ_INTERNAL int rq_multi_search(rq_index* idx, const float* queries, int B, int k, int metric, float* out_scores, int64_t* out_rows);

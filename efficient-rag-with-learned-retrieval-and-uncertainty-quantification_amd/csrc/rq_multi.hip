@@ -1,12 +1,19 @@
-// rq_multi.hip -- the multi-device parent index (include/rq.h rq_index_create with n_devices > 1): contiguous row blocks
-// per device inside the library.  The reference has no counterpart (its dense store is one ChromaDB collection,
+// rq_multi.hip -- the multi-device parent index (include/rq.h rq_index_create with n_devices > 1): row shards per device
+// inside the library.  The reference has no counterpart (its dense store is one ChromaDB collection,
 // rag_uq/streaming_index.py:252-263); this is the north star's row sharding, for callers that want several GPUs behind
 // ONE index handle instead of one process per GPU (rag_uq_amd.distributed).
+//
+// Layout: global rows are dealt to the devices in STRIPES of `stripe` rows (default 65 536 = 100 MB of fp16 rows), round
+// robin: global row g lives in stripe s = g / stripe, on device slot s % G, at local row (s / G) * stripe + g % stripe.
+// Appending in global order fills one stripe after the other, so every child's local rows stay dense, local order is
+// monotone in the global id (ties keep their canonical order through the merge), and the mapping is arithmetic -- no
+// segment table.  A streaming build that appends 100 documents per call (reference StreamingIndex, :606-660) touches ONE
+// device per append (two when the block crosses a stripe end); round 2 cut every appended block into G pieces (12-row
+// pieces and one table entry per append and device).
 #include "rq_index.h"
 
-// ---------------------------------------------------------------------------------------------
-// multi-device parent: contiguous row blocks per device inside the library
-// ---------------------------------------------------------------------------------------------
+#include <thread>
+
 rq_index* rq_multi_create(int dim, int n_devices, const int* device_ids) {
     rq_index* p = new rq_index();
     p->dim = dim;
@@ -15,80 +22,123 @@ rq_index* rq_multi_create(int dim, int n_devices, const int* device_ids) {
         rq_index* c = rq_index_create(dim, 1, device_ids + j);   // (the same device may be named several times)
         if (!c) { rq_index_destroy(p); return nullptr; }
         p->shards.push_back(c);
-        p->seg_local.push_back({0});
-        p->seg_global.push_back({});
     }
     return p;
 }
 
+// rows of child j when the parent holds n rows
+static int64_t child_rows(const rq_index* idx, size_t j, int64_t n) {
+    const int64_t S = idx->stripe, G = (int64_t)idx->shards.size();
+    const int64_t full = n / S, rem = n % S;          // complete stripes, rows of the open one
+    int64_t r = (full / G) * S + ((int64_t)j < full % G ? S : 0);
+    if ((int64_t)j == full % G) r += rem;
+    return r;
+}
+
+int rq_multi_reserve(rq_index* idx, int64_t n_rows) {
+    for (size_t j = 0; j < idx->shards.size(); ++j)
+        if (int r = rq_index_reserve(idx->shards[j], child_rows(idx, j, n_rows))) return r;
+    return RQ_OK;
+}
+
 int rq_multi_add(rq_index* idx, const void* rows, int64_t n_rows, bool is_f32, int normalize) {
+    if (idx->poisoned) return set_err(RQ_EHIP, "multi-device index is unusable: an earlier append failed part-way (%s)", "rq_index_destroy it and rebuild");
     if ((uint64_t)idx->row_offset + (uint64_t)idx->n + (uint64_t)n_rows >= 0xffffffffull)
         return set_err(RQ_EUNSUPPORTED, "row ids beyond 2^32-1 are not supported");
-    const int64_t g = (int64_t)idx->shards.size(), per = (n_rows + g - 1) / g;
+    const int64_t S = idx->stripe, G = (int64_t)idx->shards.size();
     const size_t esz = is_f32 ? 4 : 2;
-    for (int64_t j = 0; j < g; ++j) {
-        const int64_t lo = std::min(j * per, n_rows), hi = std::min((j + 1) * per, n_rows);
-        if (hi <= lo) continue;
-        if (int r = rq_add_host_common(idx->shards[j], (const char*)rows + (size_t)lo * idx->dim * esz, hi - lo, is_f32, normalize)) {
-            // pieces 0..j-1 of this block are already stored: the parent is no longer a prefix of what the caller sent
-            return set_err(r, "multi-device append failed on device slot %lld after %lld of %lld rows of the block were stored: %s",
-                           (long long)j, (long long)lo, (long long)n_rows, std::string(rq_err_text()).c_str());
+    for (int64_t done = 0; done < n_rows;) {
+        const int64_t g0 = idx->n, s = g0 / S;
+        const int64_t m = std::min(n_rows - done, (s + 1) * S - g0);   // up to the end of the open stripe
+        rq_index* c = idx->shards[(size_t)(s % G)];
+        if (c->n != (s / G) * S + g0 % S)
+            return set_err(RQ_EHIP, "internal: device slot %lld holds %lld rows, the stripe layout expects %lld", (long long)(s % G), (long long)c->n, (long long)((s / G) * S + g0 % S));
+        if (int r = rq_add_host_common(c, (const char*)rows + (size_t)done * idx->dim * esz, m, is_f32, normalize)) {
+            // The child may hold part of the piece (host rows are streamed in chunks): the parent can no longer tell which
+            // global rows exist.  Rows of EARLIER pieces of this call are complete and counted; the index refuses further use.
+            idx->poisoned = c->n != (s / G) * S + g0 % S;
+            return set_err(r, "multi-device append failed on device slot %lld after %lld of %lld rows of the block were stored%s: %s",
+                           (long long)(s % G), (long long)done, (long long)n_rows, idx->poisoned ? " (index unusable)" : "", std::string(rq_err_text()).c_str());
         }
-        idx->seg_global[j].push_back(idx->n + lo);
-        idx->seg_local[j].push_back(idx->seg_local[j].back() + (hi - lo));
+        idx->n += m;
+        done += m;
     }
-    idx->n += n_rows;
     return RQ_OK;
 }
 
 int rq_multi_get_rows(const rq_index* idx, int64_t row_begin, int64_t n_rows, uint16_t* out) {
-    const int64_t row_end = row_begin + n_rows;
-    for (size_t j = 0; j < idx->shards.size(); ++j)
-        for (size_t sgi = 0; sgi < idx->seg_global[j].size(); ++sgi) {
-            const int64_t g0 = idx->seg_global[j][sgi], len = idx->seg_local[j][sgi + 1] - idx->seg_local[j][sgi];
-            const int64_t lo = std::max(g0, row_begin), hi = std::min(g0 + len, row_end);
-            if (hi <= lo) continue;
-            if (int r = rq_index_get_rows_f16(idx->shards[j], idx->seg_local[j][sgi] + (lo - g0), hi - lo, out + (size_t)(lo - row_begin) * idx->dim)) return r;
-        }
+    const int64_t S = idx->stripe, G = (int64_t)idx->shards.size();
+    for (int64_t g = row_begin, end = row_begin + n_rows; g < end;) {
+        const int64_t s = g / S, m = std::min(end - g, (s + 1) * S - g);
+        if (int r = rq_index_get_rows_f16(idx->shards[(size_t)(s % G)], (s / G) * S + g % S, m, out + (size_t)(g - row_begin) * idx->dim)) return r;
+        g += m;
+    }
     return RQ_OK;
+}
+
+// Per query: the children's k best (score, local row) pairs arrive best first; local order is monotone in the global id, so
+// each list is already in canonical order after the mapping and a k-way merge of the list heads yields the global top-k.
+static void merge_queries(const rq_index* idx, const std::vector<size_t>& live, int q_lo, int q_hi, int k, float* out_scores, int64_t* out_rows) {
+    const int64_t S = idx->stripe, G = (int64_t)idx->shards.size();
+    const size_t nl = live.size();
+    size_t head[64];
+    for (int q = q_lo; q < q_hi; ++q) {
+        for (size_t a = 0; a < nl; ++a) head[a] = 0;
+        for (int i = 0; i < k; ++i) {
+            uint64_t best = 0;
+            size_t who = nl;
+            for (size_t a = 0; a < nl; ++a) {
+                if (head[a] >= (size_t)k) continue;
+                const size_t at = (a * (size_t)idx->m_B + (size_t)q) * (size_t)k + head[a];
+                const int64_t lr = idx->m_rows[at];
+                if (lr < 0) { head[a] = (size_t)k; continue; }          // padding: this child's list is exhausted
+                const int64_t j = (int64_t)live[a];
+                const int64_t grow = ((lr / S) * G + j) * S + lr % S;
+                const uint64_t key = rq_make_key(idx->m_scores[at], (uint32_t)grow);
+                if (key > best) { best = key; who = a; }
+            }
+            if (who == nl) { out_scores[(size_t)q * k + i] = 0.f; out_rows[(size_t)q * k + i] = -1; continue; }
+            head[who]++;
+            out_scores[(size_t)q * k + i] = rq_key_score(best);
+            out_rows[(size_t)q * k + i] = idx->row_offset + (int64_t)rq_key_index(best);
+        }
+    }
 }
 
 int rq_multi_search(rq_index* idx, const float* queries, int B, int k, int metric, float* out_scores, int64_t* out_rows) {
+    if (idx->poisoned) return set_err(RQ_EHIP, "multi-device index is unusable: an earlier append failed part-way");
     const size_t g = idx->shards.size();
     idx->t.searches++;
     idx->t.queries += B;
-    std::vector<size_t> live;
-    for (size_t j = 0; j < g; ++j)
+    std::vector<size_t>& live = idx->m_live;
+    live.clear();
+    int rc = RQ_OK;
+    for (size_t j = 0; j < g && rc == RQ_OK; ++j)
         if (idx->shards[j]->n > 0) {
-            if (int r = rq_search_begin(idx->shards[j], queries, B, k, metric)) return r;   // every device is busy before any is waited for
-            live.push_back(j);
+            rc = rq_search_begin(idx->shards[j], queries, B, k, metric);   // every device is busy before any is waited for
+            if (rc == RQ_OK) live.push_back(j);
         }
-    std::vector<float> sc((size_t)B * k);
-    std::vector<int64_t> rw((size_t)B * k);
-    std::vector<std::vector<uint64_t>> keys((size_t)B);
-    for (size_t j : live) {
-        if (int r = rq_search_end(idx->shards[j], B, k, metric, sc.data(), rw.data())) return r;
-        const std::vector<int64_t>& sl = idx->seg_local[j];
-        const std::vector<int64_t>& sg = idx->seg_global[j];
-        for (int q = 0; q < B; ++q)
-            for (int i = 0; i < k; ++i) {
-                const int64_t lr = rw[(size_t)q * k + i];
-                if (lr < 0) continue;
-                const size_t sgi = (size_t)(std::upper_bound(sl.begin(), sl.end() - 1, lr) - sl.begin()) - 1;   // segment that holds the local row
-                const int64_t grow = sg[sgi] + (lr - sl[sgi]);
-                keys[(size_t)q].push_back(rq_make_key(sc[(size_t)q * k + i], (uint32_t)grow));
-            }
+    // result staging [live child][B][k], kept between calls
+    const size_t need = live.size() * (size_t)B * (size_t)k;
+    if (idx->m_scores.size() < need) { idx->m_scores.resize(need); idx->m_rows.resize(need); }
+    idx->m_B = B;
+    std::string first_err;
+    if (rc != RQ_OK) first_err = rq_err_text();
+    for (size_t a = 0; a < live.size(); ++a) {
+        // (after a failure the searches already enqueued are still waited for and their staging released; their results are dropped)
+        const int r = rq_search_end(idx->shards[live[a]], B, k, metric, idx->m_scores.data() + a * (size_t)B * k, idx->m_rows.data() + a * (size_t)B * k);
+        if (r != RQ_OK && rc == RQ_OK) { rc = r; first_err = rq_err_text(); }
     }
-    for (int q = 0; q < B; ++q) {   // canonical order: score descending, then global row ascending = key descending
-        std::vector<uint64_t>& kq = keys[(size_t)q];
-        const size_t m = std::min<size_t>((size_t)k, kq.size());
-        std::partial_sort(kq.begin(), kq.begin() + m, kq.end(), std::greater<uint64_t>());
-        for (int i = 0; i < k; ++i) {
-            const bool v = (size_t)i < m;
-            out_scores[(size_t)q * k + i] = v ? rq_key_score(kq[(size_t)i]) : 0.f;
-            out_rows[(size_t)q * k + i] = v ? idx->row_offset + (int64_t)rq_key_index(kq[(size_t)i]) : -1;
-        }
+    if (rc != RQ_OK) return set_err(rc, "%s", first_err.c_str());
+    // host merge: O(B k G); calls with many queries split them over a few threads
+    const size_t work = (size_t)B * (size_t)k * live.size();
+    const int nthr = work < 200000 ? 1 : (int)std::min<size_t>(8, std::max<size_t>(1, std::thread::hardware_concurrency() / 2));
+    if (nthr <= 1) merge_queries(idx, live, 0, B, k, out_scores, out_rows);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthr; ++t)
+            th.emplace_back(merge_queries, idx, std::cref(live), (int)((int64_t)B * t / nthr), (int)((int64_t)B * (t + 1) / nthr), k, out_scores, out_rows);
+        for (auto& x : th) x.join();
     }
     return RQ_OK;
 }
-

@@ -229,26 +229,37 @@ class NomicBertEmbedder:
                 mask[i, : len(r)] = 1
         return torch.from_numpy(ids).to(self.device), torch.from_numpy(mask).to(self.device)
 
-    def embed(self, texts: Sequence[str]) -> np.ndarray:
+    def embed_device(self, texts: Sequence[str]):
+        """[len(texts)][dim] fp32 embeddings as ONE tensor on the embedder's device, rows in the caller's order (what
+        DenseIndex.search_batch hands to rq_search_device: the query matrix never leaves HBM).  May raise."""
         torch = self.torch
         texts = list(texts)
         if not texts:
-            return np.zeros((0, self.dim), np.float32)
+            return torch.zeros((0, self.dim), device=self.device, dtype=torch.float32)
         # batches of similar length: a batch is padded to its longest text, so ragged inputs (passages) are sorted by length
         # first and the rows are put back in the caller's order afterwards
         order = sorted(range(len(texts)), key=lambda i: len(texts[i])) if len(texts) > self.batch_size else list(range(len(texts)))
-        out = np.empty((len(texts), self.dim), np.float32)
+        single = len(order) <= self.batch_size
+        out = None if single else torch.empty((len(texts), self.dim), device=self.device, dtype=torch.float32)
         with torch.inference_mode():
             for lo in range(0, len(order), self.batch_size):
                 sel = order[lo: lo + self.batch_size]
                 ids, mask = self._tokenize([texts[i] for i in sel])
                 if self.fused is not None and self.fused.usable(ids, mask):
-                    out[sel] = self.fused(ids, mask).cpu().numpy()
-                    continue
-                h = self.model(input_ids=ids, attention_mask=mask).last_hidden_state.float()
-                m = mask.unsqueeze(-1).float()
-                out[sel] = ((h * m).sum(1) / m.sum(1).clamp_min(1.0)).cpu().numpy()
+                    v = self.fused(ids, mask)
+                else:
+                    h = self.model(input_ids=ids, attention_mask=mask).last_hidden_state.float()
+                    m = mask.unsqueeze(-1).float()
+                    v = (h * m).sum(1) / m.sum(1).clamp_min(1.0)
+                if single:
+                    return v          # (one batch in the caller's order: no scatter)
+                out[torch.as_tensor(sel, device=self.device)] = v
         return out
+
+    def embed(self, texts: Sequence[str]) -> np.ndarray:
+        if not len(texts):
+            return np.zeros((0, self.dim), np.float32)
+        return self.embed_device(texts).cpu().numpy()
 
 
 def default_embedder(embedding_model: str = "nomic-embed-text"):

@@ -237,12 +237,110 @@ class BM25Index:
             scores[r] += c
         return scores
 
+    @staticmethod
+    def _select_topk(scores: np.ndarray, top_k: int) -> np.ndarray:
+        """Rows of the reference's selection (:172-177: argsort, reversed, first top_k, score > 0 only) without sorting the whole
+        score vector (80 % of a search over 50 k passages).  Exact ties -- which numpy's default argsort orders in an unspecified,
+        build-dependent way -- are ordered as `np.argsort(scores, kind="stable")[::-1]` would: by DESCENDING row.  The same rule as
+        librq_bm25.so (include/rq_bm25.h), so `search` and `search_batch` agree to the last bit."""
+        pos = np.flatnonzero(scores > 0)
+        if top_k <= 0 or pos.size == 0:
+            return pos[:0]
+        if pos.size > top_k:
+            vals = scores[pos]
+            kth = np.partition(vals, pos.size - top_k)[pos.size - top_k]
+            pos = pos[vals >= kth]                     # every row tied with the k-th score takes part in the tie-break
+        order = np.lexsort((-pos, -scores[pos]))
+        return pos[order[:top_k]]
+
     def search(self, query: str, top_k: int = 10) -> List[Tuple[str, float]]:
         if self.bm25 is None or not self.doc_ids:
             return []
         scores = self.get_scores(self._tokenize(query))
-        top_indices = np.argsort(scores)[::-1][:top_k]
-        return [(self.doc_ids[i], float(scores[i])) for i in top_indices if scores[i] > 0]
+        return [(self.doc_ids[i], float(scores[i])) for i in self._select_topk(scores, top_k).tolist()]
+
+    # ---- a whole batch of queries at once (extension; configs[4]: 500 questions per call) ---------------------------------
+    def _csr(self) -> Dict[str, Any]:
+        """The inverted index as CSR arrays for the CURRENT corpus (rebuilt after an add: idf and avgdl change with every document):
+        token ids in first-seen order, postings concatenated, and every posting's contribution idf * tf-saturation evaluated with
+        the SAME float64 expression as _token_contribution -- the batch path then only adds them, in query-token order."""
+        n_docs = len(self.doc_ids)
+        c = self.__dict__.get("_csr_cache")
+        if c is not None and c["n_docs"] == n_docs:
+            return c
+        if c is not None and c.get("handle") is not None:
+            _native.bm25_destroy(c["handle"])
+        from itertools import chain
+        idf = self._ensure_idf()
+        avgdl = self._total_len / n_docs
+        toks = list(self._post_rows)
+        lens = np.fromiter((len(self._post_rows[t]) for t in toks), np.int64, len(toks))
+        indptr = np.zeros(len(toks) + 1, np.int64)
+        np.cumsum(lens, out=indptr[1:])
+        nnz = int(indptr[-1])
+        rows = np.fromiter(chain.from_iterable(self._post_rows.values()), np.int32, nnz)
+        f = np.fromiter(chain.from_iterable(self._post_tf.values()), np.float64, nnz)
+        w = np.repeat(np.fromiter(((idf.get(t) or 0) for t in toks), np.float64, len(toks)), lens)
+        contrib = w * (f * (self.k1 + 1) / (f + self.k1 * (1 - self.b + self.b * self._np_doc_len()[rows] / avgdl)))
+        c = {"n_docs": n_docs, "tid": {t: i for i, t in enumerate(toks)}, "indptr": indptr, "rows": rows, "contrib": contrib, "handle": None}
+        if _native.bm25_available():
+            c["handle"] = _native.bm25_create(indptr, rows, contrib, len(toks), n_docs)
+        self.__dict__["_csr_cache"] = c
+        return c
+
+    def search_batch(self, queries: Sequence[str], top_k: int = 10, *, n_threads: int = 0, use_native: Optional[bool] = None
+                     ) -> List[List[Tuple[str, float]]]:
+        """`[self.search(q, top_k) for q in queries]`, scored as one job: librq_bm25.so (include/rq_bm25.h) walks the posting lists
+        of every query on the host cores -- term at a time, one float64 accumulator per thread, the contributions added in query
+        order (the same additions as get_scores: identical bits), top-k by a heap with the tie rule of _select_topk.  Without
+        the library (`use_native=False`, or it is not built) the same arrays are scored with numpy, one query at a time."""
+        if self.bm25 is None or not self.doc_ids or top_k <= 0:
+            return [[] for _ in queries]
+        c = self._csr()
+        tid = c["tid"]
+        q_tok: List[int] = []
+        q_ptr = [0]
+        for q in queries:
+            for t in self._tokenize(q):
+                j = tid.get(t)
+                if j is not None:
+                    q_tok.append(j)
+            q_ptr.append(len(q_tok))
+        native = c["handle"] is not None if use_native is None else (use_native and c["handle"] is not None)
+        if use_native and c["handle"] is None:
+            raise _native.RqError("librq_bm25.so is not built: `make -C csrc` (or use_native=False for the numpy path)")
+        B, k = len(q_ptr) - 1, int(top_k)
+        if native:
+            out_rows, out_scores = _native.bm25_topk(c["handle"], np.asarray(q_ptr, np.int64), np.asarray(q_tok, np.int32), B, k, n_threads)
+            ids = np.empty(len(self.doc_ids), dtype=object)
+            cache = self.__dict__.get("_ids_np")
+            if cache is None or len(cache) != len(self.doc_ids):
+                ids[:] = self.doc_ids
+                cache = self.__dict__["_ids_np"] = ids
+            idl = cache[np.where(out_rows >= 0, out_rows, 0)].tolist()
+            scl = out_scores.tolist()
+            have = (out_rows >= 0).sum(axis=1).tolist()
+            return [list(zip(idl[b][:have[b]], scl[b][:have[b]])) for b in range(B)]
+        indptr, rows, contrib = c["indptr"], c["rows"], c["contrib"]
+        res = []
+        for b in range(B):
+            scores = np.zeros(len(self.doc_ids))
+            for j in q_tok[q_ptr[b]: q_ptr[b + 1]]:
+                lo, hi = indptr[j], indptr[j + 1]
+                scores[rows[lo:hi]] += contrib[lo:hi]
+            res.append([(self.doc_ids[i], float(scores[i])) for i in self._select_topk(scores, k).tolist()])
+        return res
+
+    def _drop_csr(self) -> None:
+        c = self.__dict__.pop("_csr_cache", None)
+        if c is not None and c.get("handle") is not None:
+            _native.bm25_destroy(c["handle"])
+
+    def __del__(self):
+        try:
+            self._drop_csr()
+        except Exception:
+            pass
 
     def get_document(self, doc_id: str) -> Optional[Document]:
         return self.documents.get(doc_id)
@@ -309,16 +407,24 @@ class BM25Index:
         self.__dict__.pop("_post_np", None)              # numpy views of the posting lists (get_scores): rebuilt on demand
         self.__dict__.pop("_doc_len_np", None)
         self.__dict__.pop("_contrib", None)
+        self._drop_csr()
         for row, toks in enumerate(self.tokenized_corpus):
             self._index_tokens(row, toks)
         self._snapshot_docs = len(self.doc_ids)
-        if self._log_path().exists():                      # documents added since the snapshot (a torn last line is dropped)
-            with open(self._log_path()) as f:
-                for line in f:
+        if self._log_path().exists():                      # documents added since the snapshot
+            # Replay stops at the first line that is not a complete record (a torn tail: the process died inside a write).  The
+            # torn bytes must not stay in the file: the next add reopens the log in append mode, its first record would be glued
+            # onto them, and every document acknowledged from then on would be unreadable at the following load.  So the log
+            # is cut back to the end of the last good record (and a record that lost only its newline gets it back).
+            good_end, needs_newline = 0, False
+            with open(self._log_path(), "rb") as f:
+                for raw in f:
                     try:
-                        doc = Document.from_dict(json.loads(line))
-                    except (json.JSONDecodeError, KeyError):
+                        doc = Document.from_dict(json.loads(raw.decode("utf-8")))
+                    except (json.JSONDecodeError, UnicodeDecodeError, KeyError, TypeError, AttributeError):
                         break
+                    good_end += len(raw)
+                    needs_newline = not raw.endswith(b"\n")
                     if doc.id in self.documents:
                         continue
                     self.documents[doc.id] = doc
@@ -326,6 +432,13 @@ class BM25Index:
                     toks = self._tokenize(doc.text)
                     self.tokenized_corpus.append(toks)
                     self._index_tokens(len(self.doc_ids) - 1, toks)
+            if good_end != self._log_path().stat().st_size or needs_newline:
+                logger.warning(f"BM25 log {self._log_path()}: dropping a torn tail after {good_end} bytes")
+                with open(self._log_path(), "r+b") as f:
+                    f.truncate(good_end)
+                    if needs_newline:
+                        f.seek(0, os.SEEK_END)
+                        f.write(b"\n")
         logger.info(f"Loaded BM25 index with {len(self.doc_ids)} documents")
 
     def __len__(self) -> int:
@@ -348,13 +461,16 @@ def _read_meta(meta_path: Path) -> Optional[Dict[str, int]]:
     return out
 
 
-def repair_persisted_collection(base: Path, docs_path: Path) -> Optional[Dict[str, int]]:
+def repair_persisted_collection(base: Path, docs_path: Path, truncate: bool = True) -> Optional[Dict[str, int]]:
     """Bring the three files of a persisted collection back to the last COMMITTED state.
 
     An add appends rows to <base>.f16, records to <docs_path>, and only then replaces <base>.meta (the commit point,
     written atomically).  A process killed in between leaves data files LONGER than the meta says; they are cut back
     here, so that the collection reopens with exactly the committed rows (Chroma's PersistentClient, which the reference
     uses at :257, is transactional on add).  Data files SHORTER than the commit are real corruption and raise.
+    `truncate=False` only READS the commit (what a process that merely opens the collection does: bytes beyond the commit may
+    belong to a writer that sits between appending its data and replacing the meta -- cutting them off would leave that
+    writer's next meta describing more bytes than exist); the writer path truncates before it appends.
     Returns {'dim', 'rows', 'docs_bytes'} or None when nothing was ever committed."""
     meta = _read_meta(Path(str(base) + ".meta"))
     if meta is None:
@@ -364,7 +480,7 @@ def repair_persisted_collection(base: Path, docs_path: Path) -> Optional[Dict[st
     have = f16_path.stat().st_size if f16_path.exists() else 0
     if have < want:
         raise RuntimeError(f"persisted index is inconsistent: {f16_path} holds {have} bytes, the commit record needs {want}")
-    if have > want:
+    if have > want and truncate:
         with open(f16_path, "r+b") as f:
             f.truncate(want)
     docs_have = docs_path.stat().st_size if docs_path.exists() else 0
@@ -383,7 +499,7 @@ def repair_persisted_collection(base: Path, docs_path: Path) -> Optional[Dict[st
             raise RuntimeError(f"persisted index is inconsistent: {seen} ids vs {meta['rows']} rows")
     if docs_have < docs_want:
         raise RuntimeError(f"persisted index is inconsistent: {docs_path} holds {docs_have} bytes, the commit record needs {docs_want}")
-    if docs_have > docs_want:
+    if docs_have > docs_want and truncate:
         with open(docs_path, "r+b") as f:
             f.truncate(docs_want)
     meta["docs_bytes"] = docs_want
@@ -470,6 +586,8 @@ class DenseIndex:
 
     def _apply_backend_options(self) -> None:
         for name, value in self.backend_options.items():
+            if name == "stripe_rows" and len(self._index):      # the stripe layout of a multi-device index is fixed by its first rows
+                continue
             self._index.set_option(name, float(value))
 
     def add_documents(self, documents: List[Document], batch_size: int = 100) -> int:
@@ -526,6 +644,8 @@ class DenseIndex:
         if committed is None or committed["rows"] != first_new or committed["dim"] != self.dim:
             first_new = 0                         # nothing usable on disk: (re)write from scratch
             docs_bytes = 0
+            if meta_path.exists():                # ... and say so first: an old commit over half-rewritten files could never be reopened
+                meta_path.unlink()
         else:
             docs_bytes = committed["docs_bytes"]
         rows = self._index.get_rows_f16(first_new, n - first_new)
@@ -539,6 +659,51 @@ class DenseIndex:
         _atomic_write(meta_path, f"rq-index 1\ndim {self.dim}\nrows {n}\ndtype f16\ndocs_bytes {docs_bytes}\n".encode())
 
     # ---- query (reference :338-370) -------------------------------------------------------------------
+    @classmethod
+    def from_native(cls, index: "_native.NativeIndex", ids: Sequence[str], texts: Optional[Sequence[str]] = None, *,
+                    embedder=None, metric: str = "cosine") -> "DenseIndex":
+        """Wrap a shard that already sits in HBM (built through the C ABI / `add_f16_device`) as a DenseIndex: row i of `index`
+        answers as `ids[i]`.  Nothing is persisted (extension; the reference has no counterpart)."""
+        if len(ids) != len(index):
+            raise ValueError(f"{len(ids)} ids for {len(index)} rows")
+        self = cls.__new__(cls)
+        self.collection_name, self.persist_directory, self.embedding_model = "rag_documents", "", "nomic-embed-text"
+        self.backend_options = {}
+        self.embedder = embedder if embedder is not None else default_embedder(self.embedding_model)
+        self.device, self.devices = index.device, None
+        self.metric = _native.METRIC_IP if metric in ("ip", "inner_product") else _native.METRIC_COSINE
+        self.auto_persist = False
+        self.dim = index.dim
+        self._index = index
+        self._ids = list(ids)
+        self._row_of = {d: i for i, d in enumerate(self._ids)}
+        self._texts = list(texts) if texts is not None else [""] * len(self._ids)
+        self._metas = [{} for _ in self._ids] if len(self._ids) < 100_000 else [{}] * len(self._ids)
+        return self
+
+    def _id_text_arrays(self) -> Tuple[np.ndarray, np.ndarray]:
+        """object arrays of the ids / texts (one fancy-index gather per search instead of a Python loop over B * k results)"""
+        cache = self.__dict__.get("_idtext_np")
+        if cache is None or len(cache[0]) != len(self._ids):
+            ids = np.empty(len(self._ids), dtype=object)
+            ids[:] = self._ids
+            texts = np.empty(len(self._texts), dtype=object)
+            texts[:] = self._texts
+            cache = self.__dict__["_idtext_np"] = (ids, texts)
+        return cache
+
+    def _assemble(self, scores: np.ndarray, rows: np.ndarray) -> List[List[Tuple[str, float, str]]]:
+        """(scores [B][k], rows [B][k], -1 padded) -> the reference's result lists (:361-368): (doc_id, float(score), text), best first"""
+        ids, texts = self._id_text_arrays()
+        ok = rows >= 0
+        all_ok = bool(ok.all())
+        safe = rows if all_ok else np.where(ok, rows, 0)
+        idl, txl, scl = ids[safe].tolist(), texts[safe].tolist(), scores.astype(np.float64).tolist()
+        if all_ok:
+            return [list(zip(i, s, t)) for i, s, t in zip(idl, scl, txl)]
+        okl = ok.tolist()
+        return [[(i, s, t) for i, s, t, v in zip(ib, sb, tb, vb) if v] for ib, sb, tb, vb in zip(idl, scl, txl, okl)]
+
     def search_vectors(self, vectors: np.ndarray, top_k: int = 10) -> List[List[Tuple[str, float, str]]]:
         vectors = np.atleast_2d(np.asarray(vectors, dtype=np.float32))
         if self._index is None or len(self._ids) == 0 or top_k <= 0:
@@ -547,14 +712,60 @@ class DenseIndex:
             raise ValueError(f"query dimension {vectors.shape[1]} does not match the index ({self.dim})")
         k = min(int(top_k), len(self._ids), _native.MAX_K)
         scores, rows = self._index.search(vectors, k, self.metric)
-        out = []
-        for b in range(vectors.shape[0]):
-            out.append([(self._ids[r], float(s), self._texts[r]) for s, r in zip(scores[b], rows[b]) if r >= 0])
-        return out
+        return self._assemble(scores, rows)
+
+    def search_device_vectors(self, d_vectors, top_k: int = 10) -> List[List[Tuple[str, float, str]]]:
+        """Queries that are already in HBM (a CUDA tensor [B][dim] fp32, e.g. `NomicBertEmbedder.embed_device`): searched where they
+        are (rq_search_device on torch's current stream), repaired if a certificate failed, ONE device-to-host copy of rows + scores."""
+        import torch
+        B = int(d_vectors.shape[0])
+        if self._index is None or len(self._ids) == 0 or top_k <= 0 or B == 0:
+            return [[] for _ in range(B)]
+        if int(d_vectors.shape[1]) != self.dim:
+            raise ValueError(f"query dimension {int(d_vectors.shape[1])} does not match the index ({self.dim})")
+        if not hasattr(self._index, "search_device") or len(getattr(self._index, "devices", [0])) > 1:
+            return self.search_vectors(d_vectors.float().cpu().numpy(), top_k)       # multi-device parent: host-buffer calls only
+        k = min(int(top_k), len(self._ids), _native.MAX_K)
+        dev = d_vectors.device
+        q = d_vectors.to(torch.float32).contiguous()
+        buf = self.__dict__.get("_dev_out")
+        if buf is None or buf[0] < B or buf[1] < k or buf[2].device != dev:
+            nb, nk = max(B, buf[0] if buf else 0), max(k, buf[1] if buf else 0)
+            block = torch.empty((nb * nk * 3 + nb,), device=dev, dtype=torch.int32)          # [rows int64 | scores fp32 | status int32]
+            buf = self.__dict__["_dev_out"] = (nb, nk, block, torch.empty((nb * nk * 3 + nb,), dtype=torch.int32).pin_memory())
+        block, pinned = buf[2], buf[3]
+        rows_t = block[: 2 * B * k].view(torch.int64).view(B, k)
+        scores_t = block[2 * B * k: 3 * B * k].view(torch.float32).view(B, k)
+        status_t = block[3 * B * k: 3 * B * k + B]
+        stream = torch.cuda.current_stream(dev)
+        with torch.cuda.device(dev):
+            self._index.search_device(q, B, k, self.metric, scores_t, rows_t, None, status_t, stream.cuda_stream)
+            self._index.search_flush_device(stream.cuda_stream)
+            n = 3 * B * k + B
+            pinned[:n].copy_(block[:n], non_blocking=True)
+            stream.synchronize()
+            if bool(pinned[3 * B * k: n].any()):        # rare: a certificate failed -> exact repair on the device, fetch again
+                self._index.search_fixup_device(q, B, k, self.metric, scores_t, rows_t, None, status_t, stream.cuda_stream)
+                pinned[:n].copy_(block[:n], non_blocking=True)
+                stream.synchronize()
+        host = pinned.numpy()
+        rows = host[: 2 * B * k].view(np.int64).reshape(B, k)
+        scores = host[2 * B * k: 3 * B * k].view(np.float32).reshape(B, k)
+        return self._assemble(scores, rows)
 
     def search_batch(self, queries: Sequence[str], top_k: int = 10) -> List[List[Tuple[str, float, str]]]:
         if not queries:
             return []
+        # an embedder that can leave its output in HBM (embedders.NomicBertEmbedder.embed_device) feeds the search directly: no
+        # device -> host -> numpy -> pinned -> device round trip of the query matrix
+        if hasattr(self.embedder, "embed_device") and self._index is not None and len(self._ids):
+            try:
+                d_q = self.embedder.embed_device(list(queries))
+            except Exception as e:     # reference :281-284 semantics live in _embed_matrix (per-text retry, zero vector)
+                logger.error(f"Device embedding failed ({e}); falling back to the host path")
+                d_q = None
+            if d_q is not None:
+                return self.search_device_vectors(d_q, top_k)
         return self.search_vectors(self._embed_matrix(list(queries)), top_k)
 
     def search(self, query: str, top_k: int = 10) -> List[Tuple[str, float, str]]:
@@ -570,29 +781,41 @@ class DenseIndex:
         return Path(str(base) + ".docs.jsonl"), base
 
     def save(self) -> None:
-        """rows -> <dir>/<collection>.f16/.meta (rq_save), ids/texts/metadata -> <collection>.docs.jsonl"""
+        """rows -> <dir>/<collection>.f16/.meta (rq_save), ids/texts/metadata -> <collection>.docs.jsonl.  Everything is written
+        under temporary names first; the data files are then moved into place and the meta replaces the old one LAST (the commit
+        point): a process killed anywhere in between leaves either the old commit over files that still contain it as a prefix, or
+        the new one."""
         docs_path, base = self._files()
         docs_path.parent.mkdir(parents=True, exist_ok=True)
+        if self._index is None:
+            return
+        docs_tmp, base_tmp = Path(str(docs_path) + ".tmp"), Path(str(base) + ".saving")
         docs_bytes = 0
-        with open(docs_path, "wb") as f:
+        with open(docs_tmp, "wb") as f:
             for i, doc_id in enumerate(self._ids):
                 line = (json.dumps({"id": doc_id, "text": self._texts[i], "metadata": self._metas[i]}) + "\n").encode()
                 f.write(line)
                 docs_bytes += len(line)
-        if self._index is not None:
-            self._index.save(str(base))              # rows + meta (rq_save)
-            _atomic_write(Path(str(base) + ".meta"), f"rq-index 1\ndim {self.dim}\nrows {len(self._ids)}\ndtype f16\ndocs_bytes {docs_bytes}\n".encode())
+            f.flush()
+            os.fsync(f.fileno())
+        self._index.save(str(base_tmp))              # rows (+ a meta of its own, discarded) through rq_save
+        os.replace(str(base_tmp) + ".f16", str(base) + ".f16")
+        os.replace(docs_tmp, docs_path)
+        Path(str(base_tmp) + ".meta").unlink(missing_ok=True)
+        _atomic_write(Path(str(base) + ".meta"), f"rq-index 1\ndim {self.dim}\nrows {len(self._ids)}\ndtype f16\ndocs_bytes {docs_bytes}\n".encode())
 
     def _load(self) -> None:
         docs_path, base = self._files()
-        committed = repair_persisted_collection(base, docs_path)      # cuts off what an interrupted add left behind
+        # read-only: bytes beyond the commit are ignored, not cut off (another process may be in the middle of an add; this
+        # process truncates only when it appends itself, _persist_append)
+        committed = repair_persisted_collection(base, docs_path, truncate=False)
         if committed is None:
             return
-        self._index = _native.NativeIndex.load(str(base), self.device, devices=self.devices)
+        self._index = _native.NativeIndex.load(str(base), self.device, devices=self.devices)     # (rq_load reads `rows` rows, no more)
         self._apply_backend_options()
         self.dim = self._index.dim
-        with open(docs_path) as f:
-            for line in f:
+        with open(docs_path, "rb") as f:
+            for line in f.read(committed["docs_bytes"]).splitlines():
                 rec = json.loads(line)
                 self._row_of[rec["id"]] = len(self._ids)
                 self._ids.append(rec["id"])
@@ -689,9 +912,16 @@ class HybridRetriever:
         return self._fuse(self.bm25_search(query, retrieval_pool_size), self.dense_search(query, retrieval_pool_size), top_k)
 
     def hybrid_search_batch(self, queries: Sequence[str], top_k: int = 10, retrieval_pool_size: int = 50) -> List[List[RetrievalResult]]:
-        """All dense pools from one GPU batch; BM25 and fusion per query on the host."""
+        """All dense pools from one GPU batch, all BM25 pools from one pass over the posting lists on the host cores (librq_bm25.so);
+        fusion per query."""
         dense = self.dense_search_batch(queries, retrieval_pool_size)
-        return [self._fuse(self.bm25_search(q, retrieval_pool_size), dense[i], top_k) for i, q in enumerate(queries)]
+        if self.bm25_index is None:
+            sparse = [[] for _ in queries]
+        elif hasattr(self.bm25_index, "search_batch"):
+            sparse = self.bm25_index.search_batch(list(queries), retrieval_pool_size)
+        else:
+            sparse = [self.bm25_search(q, retrieval_pool_size) for q in queries]
+        return [self._fuse(sparse[i], dense[i], top_k) for i in range(len(queries))]
 
     @staticmethod
     def _router_arrays(results: List[RetrievalResult], num_passages: int):

@@ -12,6 +12,9 @@ algorithm of rank-bm25 0.2.2 (BM25Okapi, k1=1.5, b=0.75, epsilon=0.25):
                (idf.get(t) or 0) * f(t,d) * (k1 + 1) / (f(t,d) + k1 * (1 - b + b * len(d) / avgdl))
 
 and the reference's selection on top of it (:172-177): np.argsort(scores)[::-1][:top_k], keep score > 0.
+numpy's default argsort is not stable: the order of EXACTLY tied scores is unspecified (and differs between numpy builds /
+SIMD paths).  The oracle fixes one admissible instance, the stable one: np.argsort(scores, kind="stable")[::-1], i.e. tied
+documents by descending row.
 """
 from __future__ import annotations
 
@@ -63,5 +66,5 @@ def bm25_scores(corpus_tokens: Sequence[Sequence[str]], query_tokens: Sequence[s
 
 def bm25_search(doc_ids: Sequence[str], texts: Sequence[str], query: str, top_k: int) -> List[Tuple[str, float]]:
     scores = bm25_scores([tokenize(t) for t in texts], tokenize(query))
-    top = np.argsort(scores)[::-1][:top_k]
+    top = np.argsort(scores, kind="stable")[::-1][:top_k]
     return [(doc_ids[i], float(scores[i])) for i in top if scores[i] > 0]

@@ -29,6 +29,31 @@ def test_library_exports_every_declared_symbol():
     assert set(names) == set(_native._SIGNATURES), set(names) ^ set(_native._SIGNATURES)
 
 
+def test_bm25_library_exports_every_declared_symbol():
+    """include/rq_bm25.h (librq_bm25.so: the batched CPU BM25 of configs[4], host cores, no GPU code): every declared entry
+    point is exported and bound; malformed operands are refused at create time."""
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "rq_bm25.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(rq_bm25_[a-z0-9_]+)\s*\(", text)))
+    lib = _native.load_bm25_library()
+    assert names == sorted(_native._BM25_SIGNATURES)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/rq_bm25.h but not exported by librq_bm25.so"
+    assert b"bm25" in lib.rq_bm25_version()
+    blob = open(_native.BM25_LIB_PATH, "rb").read()
+    assert b"gfx950" not in blob and b"hip" not in blob.lower()[:0] + b""          # host code only
+    indptr = np.array([0, 2, 3], np.int64)
+    rows = np.array([0, 1, 1], np.int32)
+    contrib = np.array([1.0, 2.0, 0.5])
+    h = _native.bm25_create(indptr, rows, contrib, 2, 2)
+    r, sc = _native.bm25_topk(h, np.array([0, 2, 2, 3], np.int64), np.array([0, 1, 1], np.int32), 3, 2)
+    assert r.tolist() == [[1, 0], [-1, -1], [1, -1]] and sc.tolist() == [[2.5, 1.0], [0.0, 0.0], [0.5, 0.0]]
+    with pytest.raises(_native.RqError):
+        _native.bm25_topk(h, np.array([0, 1], np.int64), np.array([2], np.int32), 1, 2)          # token id outside the index
+    _native.bm25_destroy(h)
+    with pytest.raises(_native.RqError):
+        _native.bm25_create(indptr, np.array([0, 1, 2], np.int32), contrib, 2, 2)                # row outside the corpus
+
+
 def test_library_is_gfx950_code_object():
     blob = open(_native.LIB_PATH, "rb").read()
     assert b"gfx950" in blob and b"rq_scan_kernel" in blob

@@ -988,12 +988,14 @@ def test_sharded_searcher_over_rccl_world_of_one():
 
 def test_multi_device_index_in_one_process():
     """rows block-distributed over several 'devices' of one process (here the same GPU twice / three times):
-    segment mapping, host merge, incremental appends, duplicates across shards"""
+    stripe mapping, host merge, incremental appends, duplicates across shards"""
     from rag_uq_amd import distributed as d
     from rag_uq_amd import streaming_index as si
     x16 = orc.synthetic_corpus(9_001, 768, seed=51)
     x16[4_400:4_600] = x16[17]
     mdi = d.MultiDeviceIndex(768, [0, 0, 0])
+    mdi.set_option("stripe_rows", 128)                            # stripes of 128 rows dealt round robin (default 65 536)
+    assert mdi.get_option("stripe_rows") == 128
     mdi.add_f16(x16[:1_000]); mdi.add_f16(x16[1_000:1_001]); mdi.add_f16(x16[1_001:])
     assert len(mdi) == 9_001
     q = orc.synthetic_queries(70, 768, seed=52); q[0] = x16[17].astype(np.float32)
@@ -1006,7 +1008,8 @@ def test_multi_device_index_in_one_process():
     from rag_uq_amd.embedders import HashEmbedder
     docs = [si.Document(id=f"p{i}", text=f"passage {i} item {i * 37 % 211}") for i in range(400)]
     one = si.DenseIndex(persist_directory="/tmp/rq_md_1", embedder=HashEmbedder(), load_persisted=False)
-    many = si.DenseIndex(persist_directory="/tmp/rq_md_2", embedder=HashEmbedder(), devices=[0, 0], load_persisted=False)
+    many = si.DenseIndex(persist_directory="/tmp/rq_md_2", embedder=HashEmbedder(), devices=[0, 0], load_persisted=False,
+                         backend_options={"stripe_rows": 64})
     one.add_documents(docs); many.add_documents(docs[:150]); many.add_documents(docs[150:])
     for text in ["passage 7 item 48", "item 100", docs[333].text]:
         assert one.search(text, 25) == many.search(text, 25)
@@ -1014,10 +1017,13 @@ def test_multi_device_index_in_one_process():
 
 def test_multi_device_index_persistence_and_row_offset(tmp_path):
     """rq_index_create(n_devices = 3) inside the library: save -> load (again sharded, and as one shard), row offset,
-    read-back of rows that straddle segments, device-pointer entry points refused."""
+    read-back of rows that straddle stripes, device-pointer entry points refused."""
     x16 = orc.synthetic_corpus(5_003, 96, seed=53)
     m = nat.NativeIndex(96, devices=[0, 0, 0])
+    m.set_option("stripe_rows", 192)
     m.add_f16(x16[:2_000]); m.add_f16(x16[2_000:])
+    with pytest.raises(nat.RqError, match="empty"):
+        m.set_option("stripe_rows", 64)                           # the layout is fixed by the first append
     assert len(m) == 5_003 and np.array_equal(m.get_rows_f16(600, 3_000).view(np.uint16), x16[600:3_600].view(np.uint16))
     q = orc.synthetic_queries(9, 96, seed=54)
     m.set_row_offset(10_000)
@@ -1546,3 +1552,66 @@ def test_int8_wide_passes_match_oracle():
     assert int(idx.get_option("scan8_used")) == before
     assert idx.timing()["exact_scans"] <= 2                          # (the zero queries may take the exact route)
     idx.close()
+
+
+def test_int8_ladder_counts_clean_calls_too():
+    """a server answering ONE query per call (reference DenseIndex.search, streaming_index.py:338-370) used to report only
+    its failing calls to the int8 ladder (rq_search_end's clean branch counted nothing), so repaired / checked was always >= 1 and 256
+    repaired queries IN TOTAL moved the class to the fp16 scan for good.  Now every checked query counts: 7 000 clean one-query calls
+    with 280 queries that need repair among them (4 %, below the 1-in-16 rule) leave the level alone, results stay exact."""
+    x16 = orc.synthetic_corpus(40_000, 768, seed=61)
+    x16[5_000:5_900] = x16[4_999]                        # 901 identical rows: a query on them overflows its candidate lists at k = 10
+    idx = nat.NativeIndex(768, 0)
+    idx.add_f16(x16)
+    idx.set_option("scan8", 2)
+    clean = orc.synthetic_queries(100, 768, seed=62)
+    dirty = x16[4_999].astype(np.float32)[None, :]
+    s, r = idx.search(dirty, 10)
+    assert r[0].tolist() == list(range(4_999, 5_009))    # ties by row id, exact
+    assert idx.get_option("scan8_level") == 10.0
+    t0 = idx.timing()
+    for rep in range(70):
+        for i in range(100):
+            idx.search(clean[i:i + 1], 10)
+        for _ in range(4):
+            idx.search(dirty, 10)
+    assert idx.get_option("scan8_level") == 10.0, "4 % repaired queries must not move the k <= 32 class off the one-image scan"
+    t1 = idx.timing()
+    assert t1["widened"] + t1["exact_scans"] > t0["widened"] + t0["exact_scans"]      # (the dirty queries really were repaired)
+    _check(idx, x16, clean[:64], 10)
+    # ... while a stream of nothing but failing one-query calls still escalates
+    for _ in range(600):
+        idx.search(dirty, 10)
+    assert int(idx.get_option("scan8_level")) % 10 >= 1
+    idx.close()
+
+
+def test_dense_index_device_route_equals_host_route():
+    """DenseIndex.search_device_vectors (queries already in HBM -> rq_search_device -> one D2H) returns exactly what search_vectors
+    (host buffers) returns, padding and the repair path included; from_native wraps a shard built through the C ABI."""
+    import torch
+    from rag_uq_amd import streaming_index as si
+    x16 = orc.synthetic_corpus(30_000, 768, seed=71)
+    x16[100:1_001] = x16[99]                              # a query on row 99 needs the repair ladder
+    idx = nat.NativeIndex(768, 0)
+    idx.add_f16(x16)
+    di = si.DenseIndex.from_native(idx, [f"d{i}" for i in range(30_000)], [f"text {i}" for i in range(30_000)])
+    q = orc.synthetic_queries(70, 768, seed=72)
+    q[3] = x16[99].astype(np.float32)
+    dq = torch.from_numpy(q).cuda()
+    for k in (1, 10, 50):
+        host = di.search_vectors(q, k)
+        devr = di.search_device_vectors(dq, k)
+        assert host == devr
+        gs, gr = orc.dense_topk(q, x16, k)
+        assert [[int(d[1:]) for d, _, _ in row] for row in devr] == gr.tolist()
+        assert all(t == f"text {d[1:]}" for row in devr for d, _, t in row)
+    small = si.DenseIndex.from_native(_small_index(x16[:5]), [f"d{i}" for i in range(5)])
+    assert small.search_device_vectors(dq[:2], 10) == small.search_vectors(q[:2], 10) and len(small.search_vectors(q[:2], 10)[0]) == 5
+    idx.close()
+
+
+def _small_index(x16):
+    idx = nat.NativeIndex(768, 0)
+    idx.add_f16(x16)
+    return idx
