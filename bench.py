@@ -137,11 +137,18 @@ def main() -> None:
             self.status_host = torch.zeros((N_QUERY_BATCHES, B), dtype=torch.int32).pin_memory()
             self.status_np = self.status_host.numpy()          # (view made once, outside the timed region)
             self.pending = {"n": 0, "ring": 0, "ev": [None, None]}
+            self.trains = None
             if use_comm:
                 self.ring = [torch.zeros((GATHER_EVERY, B, k), device=dev, dtype=torch.int64) for _ in range(2)]
                 self.gathered = [torch.zeros((world, GATHER_EVERY, B, k), device=dev, dtype=torch.int64) for _ in range(2)]
                 self.m_scores = torch.empty((GATHER_EVERY * B, k), device=dev)
                 self.m_rows = torch.empty((GATHER_EVERY * B, k), device=dev, dtype=torch.int64)
+                # N > 1: the GATHER_EVERY searches between two all-gathers are enqueued by ONE library call (rq_search_train_device):
+                # a 125k-row shard answers a batch in ~25 us, a Python loop with two ctypes calls per batch costs 7-8 us of that
+                if GATHER_EVERY == N_QUERY_BATCHES and GATHER_EVERY % len(streams) == 0 and use_hint and os.environ.get("RQ_BENCH_TRAIN", "1") == "1":
+                    sl = self.slots
+                    self.trains = [idx.make_train(qs, [o["scores"] for o in sl], [o["rows"] for o in sl], [self.ring[r][j] for j in range(GATHER_EVERY)],
+                                                  [o["status"] for o in sl], [st.cuda_stream for st in streams], qs[:len(streams)]) for r in range(2)]
 
         def flush(self):
             """all-gather the local keys of the pending batches (one RCCL call) and merge them on the GPU"""
@@ -179,6 +186,18 @@ def main() -> None:
                 pending["n"] += 1
                 if pending["n"] == GATHER_EVERY:
                     self.flush()
+
+        def run_steps(self, n: int) -> None:
+            i = 0
+            while i < n:
+                if self.trains is not None and self.pending["n"] == 0 and i % N_QUERY_BATCHES == 0 and n - i >= GATHER_EVERY:
+                    self.idx.search_train_device(self.trains[self.pending["ring"]], B, k, nat.METRIC_COSINE)
+                    self.pending["n"] = GATHER_EVERY
+                    self.flush()
+                    i += GATHER_EVERY
+                else:
+                    self.step(i)
+                    i += 1
 
         def finish(self):
             """End of a timed run: the certificate status of every slot rides home in stream order (one 4 KB copy into pinned
@@ -241,8 +260,7 @@ def main() -> None:
             idx.set_option("scan8", SCAN_OPT[scan])
             idx.set_option("profile", 0)
             self.preheat()
-            for i in range(warmup):
-                self.step(i)
+            self.run_steps(warmup)
             self.flush()
             self.finish()        # the end-of-run sequence once before the timed region: the first numpy reduction / nonzero of a process cost
             self.fixup_all(max(warmup, 1))     # ~90 us of lazy initialisation on the host (measured), which a 20-step run would otherwise carry
@@ -256,8 +274,7 @@ def main() -> None:
             scan8_before = int(idx.get_option("scan8_used"))
             sync_all()
             t0 = time.perf_counter()
-            for i in range(steps):
-                self.step(i)
+            self.run_steps(steps)
             t_enq = time.perf_counter()
             self.flush()
             self.finish()
@@ -403,6 +420,7 @@ def main() -> None:
                                + ("int8 image of the fp16 rows (768 B per row)" if int8_scan else "the fp16 rows (1536 B per row)"),
                    "scan": SCAN_TEXT[int8_scan], "scan_option": args.scan,
                    "rows_per_gpu": n_local, "streams": len(streams), "pipeline": args.pipeline, "next_batch_hint": use_hint, "gather_every": GATHER_EVERY if use_comm else 0,
+                   "enqueue": "rq_search_train_device (one library call per gather period)" if loop.trains is not None else "rq_search_device per step",
                    "parallelism": f"row-shard x{world}", "ranks_seen": ranks_seen},
         "roofline": roofline_of(main_r, iso, n_local, live_events),
         "repaired_queries": main_r["fixed"],
@@ -611,7 +629,7 @@ def structured_leg(nat, torch, np, dev, n, k, Loop, sync_all):
                 qs.append(q)
             loop = Loop(idx, qs)
             entry = {}
-            for scan in ("fp16", "int8"):
+            for scan in ("fp16", "int8", "auto"):
                 r = loop.timed(scan, 64, 48, False)
                 chk = loop.exact_fp64_check(r, 2)
                 entry[scan] = {"us_per_step": r["elapsed"] / 64 * 1e6, "queries_per_s": 64 * B / r["elapsed"], "repaired_in_timed_steps": r["fixed"],
@@ -621,6 +639,9 @@ def structured_leg(nat, torch, np, dev, n, k, Loop, sync_all):
             del loop
         idx.close()
         del idx
+    res["operands"] = ("fp16 = the fp16 rows (option scan8 = 0); int8 = the int8 image FORCED (scan8 = 2: round 2's fixed start levels, the ladder moves only after "
+                       "repairs); auto = the library's rule (scan8 = 1: the ladder's start is measured when the image is built -- 64 stored rows searched through "
+                       "every rung -- so a shard the image does not pay on scans its fp16 rows from the first call)")
     res["note"] = ("scan8_level_after: per class of k (units: k <= 32, tens: larger k) 0 = one int8 image per query, 1 = two images, 2 = the class gave "
                    "the int8 image up and scans the fp16 rows; `int8` requests the image (option scan8 = 2), the library may decline per shard / class")
     return res

@@ -59,6 +59,8 @@ _SIGNATURES = {
     "rq_search_fixup_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "rq_search_flush_device": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rq_search_train_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_int]),
     "rq_nb_rope_table_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
     "rq_nb_attention_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "rq_nb_add_layernorm_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p]),
@@ -69,6 +71,7 @@ _SIGNATURES = {
     "rq_merge_keys_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
     "rq_debug_pooled": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
+    "rq_debug_bin_err": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64]),
     "rq_debug_read_bandwidth": (C.c_double, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "rq_debug_stamps": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "rq_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
@@ -227,6 +230,25 @@ class NativeIndex:
         """Announce the queries of the NEXT search_device call on `stream` (include/rq.h: rq_search_hint_next_device)."""
         _check(self._lib.rq_search_hint_next_device(self._h, _ptr(d_next_queries), int(B), C.c_void_p(stream)), "rq_search_hint_next_device")
 
+    @staticmethod
+    def make_train(d_queries: Sequence, d_scores: Sequence, d_rows: Sequence, d_keys: Optional[Sequence], d_status: Sequence,
+                   streams: Sequence[int], d_announce: Optional[Sequence] = None) -> dict:
+        """Pointer tables of a train of searches (include/rq.h rq_search_train_device), built once and re-used: batch i = d_queries[i]
+        -> d_scores[i] / d_rows[i] / d_keys[i] / d_status[i] on streams[i % len(streams)]; d_announce = the first len(streams)
+        batches of the train that follows (announced to the last launches of this one), or None."""
+        n, ns = len(d_queries), len(streams)
+        ann = list(d_announce) if d_announce is not None else []
+        ann = (ann + [None] * ns)[:ns]
+        addr = lambda a: 0 if a is None else (_ptr(a).value or 0)
+        tab = lambda seq: (C.c_void_p * len(seq))(*[addr(a) for a in seq])
+        return {"n": n, "ns": ns, "q": tab(list(d_queries) + ann), "scores": tab(d_scores), "rows": tab(d_rows),
+                "keys": tab(d_keys) if d_keys is not None else None, "status": tab(d_status), "streams": (C.c_void_p * ns)(*[int(s) for s in streams]),
+                "keep": (d_queries, d_scores, d_rows, d_keys, d_status, ann)}
+
+    def search_train_device(self, train: dict, B: int, k: int, metric: int = METRIC_COSINE) -> None:
+        _check(self._lib.rq_search_train_device(self._h, train["n"], train["q"], int(B), int(k), int(metric), train["scores"], train["rows"],
+                                                train["keys"], train["status"], train["streams"], train["ns"]), "rq_search_train_device")
+
     def search_flush_device(self, stream: int = 0) -> None:
         _check(self._lib.rq_search_flush_device(self._h, C.c_void_p(stream)), "rq_search_flush_device")
 
@@ -237,6 +259,11 @@ class NativeIndex:
     def debug_pooled(self, query: int, max_bins: int, stream: int = 0) -> np.ndarray:
         out = np.empty((int(max_bins),), dtype=np.float32)
         n = _check(self._lib.rq_debug_pooled(self._h, C.c_void_p(stream), int(query), _ptr(out), int(max_bins)), "rq_debug_pooled")
+        return out[:n]
+
+    def debug_bin_err(self, max_bins: int) -> np.ndarray:
+        out = np.empty((int(max_bins),), dtype=np.float32)
+        n = _check(self._lib.rq_debug_bin_err(self._h, _ptr(out), int(max_bins)), "rq_debug_bin_err")
         return out[:n]
 
     def read_bandwidth(self, iters: int = 20, nt: int = -1, wg_per_cu: int = 8) -> float:

@@ -47,9 +47,9 @@ static int flush_all(rq_index* idx);   // launches every tail still waiting for 
 static const size_t RQ_MAX_STREAM_CTX = 8;
 
 static void drop_x8(rq_index* idx) {
-    void* p[] = {idx->x8, idx->scale8_cos, idx->scale8_ip};
+    void* p[] = {idx->x8, idx->scale8_cos, idx->scale8_ip, idx->binerr8};
     for (void* q : p) if (q) (void)hipFree(q);
-    idx->x8 = nullptr; idx->scale8_cos = nullptr; idx->scale8_ip = nullptr;
+    idx->x8 = nullptr; idx->scale8_cos = nullptr; idx->scale8_ip = nullptr; idx->binerr8 = nullptr;
     idx->x8_valid = 0; idx->max_e8 = 0.0;
 }
 
@@ -163,7 +163,7 @@ extern "C" void rq_index_destroy(rq_index* idx) {
     for (auto& ev : idx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (idx->hs_pin) (void)hipHostFree(idx->hs_pin);
     if (idx->hs_pin_q) (void)hipHostFree(idx->hs_pin_q);
-    void* p[] = {idx->add_stage, idx->x, idx->rownorm64, idx->inv_norm, idx->ones, idx->x8, idx->scale8_cos, idx->scale8_ip, idx->d_stat8, idx->d_maxnorm, idx->h_dq, idx->h_dscores, idx->h_drows, idx->h_dstatus, idx->hs_dev, idx->dbg_stamps};
+    void* p[] = {idx->add_stage, idx->x, idx->rownorm64, idx->inv_norm, idx->ones, idx->x8, idx->scale8_cos, idx->scale8_ip, idx->binerr8, idx->d_stat8, idx->d_maxnorm, idx->h_dq, idx->h_dscores, idx->h_drows, idx->h_dstatus, idx->hs_dev, idx->dbg_stamps};
     for (void* q : p) if (q) (void)hipFree(q);
     if (idx->own_stream) (void)hipStreamDestroy(idx->own_stream);
     delete idx;
@@ -272,6 +272,7 @@ static void scan8_reset_levels(rq_index* idx) {
         idx->scan8_level[c] = idx->scan8_split < 0 ? c : (idx->scan8_split ? 1 : 0);
         idx->scan8_checked[c] = idx->scan8_repaired[c] = 0;
     }
+    idx->calib_rows = 0;   // "scan8" = 1: the next search that brings the image up to date calibrates again
 }
 
 extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
@@ -308,9 +309,11 @@ extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     else if (s == "epi" || s == "fused_epi") idx->epi = (int)v != 0;   // selection form of the 64-query scan (default variant and fused launch): 1 = positions inside the scores, 0 = compare / select
     else if (s == "profile_legacy") idx->profile_legacy = (int)v != 0;   // time scans with hipEventRecord around the launch (round 1) instead of dispatch-attached events
     else if (s == "scan8") { if (v < 0 || v > 2) return set_err(RQ_EINVAL, "scan8 must be 0, 1 or 2"); idx->scan8 = (int)v; scan8_reset_levels(idx); }   // see run_pipeline
+    else if (s == "wide256_8") { if (v != 0 && (v < 20 || v > 22)) return set_err(RQ_EINVAL, "wide256_8: 0 (off) or a 256-query int8 variant of csrc/rq_scan_wide.hip (20..22)"); idx->wide256_8 = (int)v; }
     else if (s == "wide8") idx->wide8 = (int)v != 0;   // calls of more than 64 queries may use 128-query passes over the int8 image
     else if (s == "scan8_split") { if (v < -1 || v > 1) return set_err(RQ_EINVAL, "scan8_split must be -1, 0 or 1"); idx->scan8_split = (int)v; scan8_reset_levels(idx); }   // see run_pipeline
     else if (s == "thr_mult8") { if (!(v >= 1.05 && v <= 2.25)) return set_err(RQ_EINVAL, "thr_mult8 %g outside 1.05..2.25", v); idx->thr_mult8 = v; }
+    else if (s == "bin_bound") idx->bin_bound = (int)v != 0;     // A/B: 0 = every bin is tested with the shard's worst row error (round 2)
     else if (s == "tail_local") idx->tail_local = (int)v != 0;   // A/B: 0 = every re-scored row's key goes to the query's global list
     else if (s == "use_hint") idx->use_hint = (int)v != 0;   // 0: rq_search_hint_next_device is ignored (A/B of the folded query preparation)
     else if (s == "poison_cand") idx->poison_cand = (int)v;   // test hook: candidate lists are filled with 0xff..ff keys before every tail
@@ -350,9 +353,20 @@ extern "C" double rq_get_option(const rq_index* idx, const char* name) {
     if (s == "thr_mult8") return idx->thr_mult8;
     if (s == "scan8_split") return idx->scan8_split;
     if (s == "wide8") return idx->wide8;
+    if (s == "wide256_8") return idx->wide256_8;
     if (s == "scan8_row_err") return idx->x8_valid == idx->n && idx->x8 ? idx->max_e8 : -1.0;   // worst row's relative int8 error (-1: image not built)
     if (s == "scan8_suspended") return (idx->scan8_level[0] == 2 ? 1.0 : 0.0) + (idx->scan8_level[1] == 2 ? 2.0 : 0.0);   // bit 0: k <= 32, bit 1: larger k
     if (s == "scan8_level") return idx->scan8_level[0] + 10.0 * idx->scan8_level[1];   // per class: 0 one image, 1 two images, 2 fp16 scan   // too many repairs behind the int8 scan (rq_search_fixup_device)
+    if (s == "scan8_calibrated_rows") return (double)idx->calib_rows;   // rows of the shard when the int8 ladder's start was last measured (0: never)
+    // "scan8_calib_ms_<class><rung>" / "scan8_calib_unc_<class><rung>" (class 0: k <= 32, 1: larger; rung 0 one image, 1 two images,
+    // 2 fp16 rows): milliseconds and uncertified queries of the 64-query sample search the calibration measured for that rung
+    for (int unc = 0; unc < 2; ++unc) {
+        const std::string pre = unc ? "scan8_calib_unc_" : "scan8_calib_ms_";
+        if (s.rfind(pre, 0) == 0 && s.size() == pre.size() + 2) {
+            const int c = s[pre.size()] - '0', l = s[pre.size() + 1] - '0';
+            if (c >= 0 && c < 2 && l >= 0 && l < 3) return unc ? (double)idx->calib_unc[c][l] : (double)idx->calib_ms[c][l];
+        }
+    }
     if (s == "scan8_used") return (double)idx->scan8_used;   // searches that scanned the int8 image
     if (s == "hints_used") return (double)idx->hints_used;   // searches that found their queries prepared by the launch before them
     if (s == "max_sub_rel") return idx->max_sub_rel;   // largest share of a row's norm that sits in fp16-subnormal elements
@@ -421,14 +435,106 @@ static int ensure_ones(rq_index* idx, hipStream_t s) {
     return RQ_OK;
 }
 
+#define RQ_SCAN8_MIN_ROWS 100000
+// ... and k <= 128 (beyond that the candidate sets of the looser bound outweigh the bytes saved)
+#define RQ_SCAN8_AUTO_MAX_K 128
+#define RQ_SCAN8_SMALL_K 32     // up to here one int8 image per query, beyond two (run_pipeline)
+#define RQ_SCAN8_MAX_ROW_ERR 0.03   // beyond that the candidate sets stop being small: such a shard keeps the fp16 scan
+
+static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metric, int nb, float* d_scores, int64_t* d_rows,
+                        uint64_t* d_keys, int* d_status, hipStream_t s, bool may_defer = false, bool force_generic = false, bool allow8 = true);
+
+// Where the int8 ladder STARTS on this shard ("scan8" = 1, the automatic rule), decided when the image is built instead of
+// after slow batches (round 2 started every shard at one image / two images and let rq_search_fixup_device escalate: a
+// clustered 1M-row corpus paid 4-8 batches of 0.5-0.7 ms, and a document-structured 125k-row shard kept an int8 scan that
+// was twice as slow as the fp16 one).  64 STORED rows, evenly spread, are searched as queries -- on-topic queries are the
+// hard case: their neighbourhoods are where the quantisation bound collects candidates -- through every rung (one image,
+// two images, fp16 rows) for each class of k (k = 10 for k <= 32, k = 100 beyond), timed with HIP events (prep + scan + tail,
+// plain sequential form, best of two).  A rung is eligible when at most 1 in 16 sample queries came back uncertified (the
+// ladder's own rule); the fastest eligible rung wins, the fp16 rows being always eligible.  Costs ~20 scans of the shard,
+// once per image build (and again when the shard has doubled).  "scan8" = 2 (always) skips this and starts as round 2 did.
+static int scan8_calibrate(rq_index* idx, hipStream_t s) {
+    if (idx->scan8 != 1 || idx->calibrating || !idx->x8 || idx->n < 64 * 64) return RQ_OK;
+    idx->calibrating = true;
+    struct Done { rq_index* i; ~Done() { i->calibrating = false; } } done{idx};
+    const int S = 64, KMAX = 100;
+    std::vector<uint16_t> h16((size_t)S * RQ_DPAD);
+    std::vector<float> h32((size_t)S * idx->dim);
+    for (int i = 0; i < S; ++i) {
+        const int64_t row = (int64_t)((double)i + 0.5) * idx->n / S;
+        HIPCHK(hipMemcpy(h16.data() + (size_t)i * RQ_DPAD, idx->x + (size_t)std::min(row, idx->n - 1) * RQ_DPAD * 2, RQ_DPAD * 2, hipMemcpyDeviceToHost));
+        for (int j = 0; j < idx->dim; ++j) {
+            _Float16 v; __builtin_memcpy(&v, &h16[(size_t)i * RQ_DPAD + j], 2);
+            h32[(size_t)i * idx->dim + j] = (float)v;
+        }
+    }
+    float* d_q = nullptr; float* d_sc = nullptr; int64_t* d_rw = nullptr; int* d_st = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = RQ_OK;
+    auto body = [&]() -> int {
+        HIPCHK(hipMalloc((void**)&d_q, h32.size() * sizeof(float)));
+        HIPCHK(hipMalloc((void**)&d_sc, (size_t)S * KMAX * sizeof(float)));
+        HIPCHK(hipMalloc((void**)&d_rw, (size_t)S * KMAX * sizeof(int64_t)));
+        HIPCHK(hipMalloc((void**)&d_st, (size_t)S * sizeof(int)));
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
+        HIPCHK(hipMemcpy(d_q, h32.data(), h32.size() * sizeof(float), hipMemcpyHostToDevice));
+        const int64_t used0 = idx->scan8_used;
+        for (int c = 0; c < 2; ++c) {
+            const int k = c == 0 ? 10 : KMAX;
+            if ((int64_t)k * 2 * 64 > idx->n) { idx->scan8_level[c] = 2; continue; }
+            float best_ms = 0.f;
+            int best = 2;
+            float ms_of[3] = {0.f, 0.f, 0.f};
+            int unc_of[3] = {0, 0, 0};
+            for (int level = 2; level >= 0; --level) {          // fp16 first: always eligible
+                idx->scan8_level[c] = level;
+                float ms = 1e30f;
+                int unc = 0;
+                for (int rep = 0; rep < 3; ++rep) {             // (the first run warms the workspace of this shape)
+                    HIPCHK(hipEventRecord(e0, s));
+                    if (int r = run_pipeline(idx, d_q, S, k, RQ_METRIC_COSINE, nb_default(idx, k), d_sc, d_rw, nullptr, d_st, s, false, false, level < 2)) return r;
+                    HIPCHK(hipEventRecord(e1, s));
+                    HIPCHK(hipEventSynchronize(e1));
+                    float t = 0.f;
+                    HIPCHK(hipEventElapsedTime(&t, e0, e1));
+                    if (rep > 0) ms = std::min(ms, t);
+                }
+                int st[64];
+                HIPCHK(hipMemcpy(st, d_st, sizeof st, hipMemcpyDeviceToHost));
+                for (int i = 0; i < S; ++i) unc += st[i] != 0;
+                ms_of[level] = ms; unc_of[level] = unc;
+                const bool eligible = level == 2 || unc * 16 <= S;
+                if (eligible && (level == 2 || ms < best_ms)) { best_ms = ms; best = level; }
+            }
+            idx->scan8_level[c] = best;
+            idx->scan8_checked[c] = idx->scan8_repaired[c] = 0;
+            for (int l = 0; l < 3; ++l) { idx->calib_ms[c][l] = ms_of[l]; idx->calib_unc[c][l] = unc_of[l]; }
+        }
+        idx->scan8_used = used0;      // (the calibration's own scans are not the caller's searches)
+        idx->calib_rows = idx->n;
+        return RQ_OK;
+    };
+    rc = body();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    void* p[] = {d_q, d_sc, d_rw, d_st};
+    for (void* q : p) if (q) (void)hipFree(q);
+    return rc;
+}
+
 // int8 scan ("scan8"): bring the int8 image of the shard up to date (rows appended since the last search that used it) and
 // read back the worst row's relative quantisation error.  One blocking 8-byte copy per append, nothing when up to date.
 static int ensure_x8(rq_index* idx, hipStream_t s) {
-    if (idx->x8 && idx->x8_valid == idx->n) return RQ_OK;
+    if (idx->x8 && idx->x8_valid == idx->n) {
+        if (idx->scan8 == 1 && idx->calib_rows == 0 && !idx->calibrating && idx->max_e8 <= RQ_SCAN8_MAX_ROW_ERR) return scan8_calibrate(idx, s);
+        return RQ_OK;
+    }
     if (!idx->x8) {
         hipError_t e = hipMalloc((void**)&idx->x8, (size_t)idx->cap * RQ_DPAD);
         if (e == hipSuccess) e = hipMalloc((void**)&idx->scale8_cos, (size_t)idx->cap * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void**)&idx->scale8_ip, (size_t)idx->cap * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&idx->binerr8, (size_t)(idx->cap / 64) * sizeof(float));
         if (e == hipSuccess && !idx->d_stat8) e = hipMalloc((void**)&idx->d_stat8, sizeof(unsigned long long));
         if (e != hipSuccess) {   // no room for the image (+50 % of the shard): not an error, the fp16 rows remain the scan operand
             drop_x8(idx);
@@ -440,25 +546,22 @@ static int ensure_x8(rq_index* idx, hipStream_t s) {
         HIPCHK(hipMemsetAsync(idx->scale8_cos, 0xff, (size_t)idx->cap * sizeof(float), s));   // pad rows: NaN (see grow)
         HIPCHK(hipMemsetAsync(idx->scale8_ip, 0xff, (size_t)idx->cap * sizeof(float), s));
         HIPCHK(hipMemsetAsync(idx->d_stat8, 0, sizeof(unsigned long long), s));
+        HIPCHK(hipMemsetAsync(idx->binerr8, 0, (size_t)(idx->cap / 64) * sizeof(float), s));
         idx->x8_valid = 0; idx->max_e8 = 0.0;
     }
-    HIPCHK(rq_quant_rows_launch(idx->x, idx->rownorm64, idx->x8_valid, idx->n, idx->x8, idx->scale8_cos, idx->scale8_ip, idx->d_stat8, s));
+    HIPCHK(rq_quant_rows_launch(idx->x, idx->rownorm64, idx->x8_valid, idx->n, idx->x8, idx->scale8_cos, idx->scale8_ip, idx->d_stat8, idx->binerr8, s));
     unsigned long long bits = 0;
     HIPCHK(hipMemcpyAsync(&bits, idx->d_stat8, sizeof bits, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     __builtin_memcpy(&idx->max_e8, &bits, sizeof bits);
     idx->x8_valid = idx->n;
+    if (idx->scan8 == 1 && idx->max_e8 <= RQ_SCAN8_MAX_ROW_ERR && (idx->calib_rows == 0 || idx->n >= 2 * idx->calib_rows))
+        return scan8_calibrate(idx, s);
     return RQ_OK;
 }
 // the shard's share of the int8 scan's bound (unit-query units; the query's own share is added per query by the tail):
 // worst row + the fp32 steps between the exact int32 sum and the bin record (two scale products, two 6-bit truncations)
 static inline float scan8_eps(const rq_index* idx) { return (float)(idx->max_e8 * 1.000001 + 2e-5); }
-#define RQ_SCAN8_MIN_ROWS 200000
-// ... and k <= 128 (beyond that the candidate sets of the looser bound outweigh the bytes saved)
-#define RQ_SCAN8_AUTO_MAX_K 128
-#define RQ_SCAN8_SMALL_K 32     // up to here one int8 image per query, beyond two (run_pipeline)
-#define RQ_SCAN8_MAX_ROW_ERR 0.03   // beyond that the candidate sets stop being small: such a shard keeps the fp16 scan
-
 static int fill_empty(int B, int k, float* d_scores, int64_t* d_rows, uint64_t* d_keys, int* d_status, hipStream_t s) {
     HIPCHK(hipMemsetAsync(d_scores, 0, (size_t)B * k * sizeof(float), s));
     HIPCHK(hipMemsetAsync(d_rows, 0xff, (size_t)B * k * sizeof(int64_t), s));
@@ -542,7 +645,7 @@ extern "C" int rq_stream_release(rq_index* idx, void* stream) {
 // One pass of the pipeline for B queries.  nb < 0: exact scan (every bin re-scored, no corpus scan).
 // may_defer: the caller accepts results that are complete only after rq_search_flush_device ("pipeline" option).
 static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metric, int nb, float* d_scores, int64_t* d_rows,
-                        uint64_t* d_keys, int* d_status, hipStream_t s, bool may_defer = false, bool force_generic = false, bool allow8 = true) {
+                        uint64_t* d_keys, int* d_status, hipStream_t s, bool may_defer, bool force_generic, bool allow8) {
     if (idx->n == 0) return fill_empty(B, k, d_scores, d_rows, d_keys, d_status, s);
     const int binrows = RQ_BIN_ROWS;
     const int nquads = (int)((idx->n + 63) / 64);
@@ -559,8 +662,9 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     const bool wide_ok = B <= 64 || (idx->wide8 && idx->wide_batch != 0 && idx->scan8_level[kclass] == 0);
     if (allow8 && idx->scan8 && idx->scan8_level[kclass] < 2 && nb >= 0 && 2 * (int64_t)nb < nbins && wide_ok && !force_generic && idx->fast_tail &&
         k <= RQ_FAST_MAX_K && (idx->scan8 == 2 || (idx->n >= RQ_SCAN8_MIN_ROWS && k <= RQ_SCAN8_AUTO_MAX_K))) {
-        if (int r = ensure_x8(idx, s)) return r;
-        use8 = idx->x8 && idx->x8_valid == idx->n && idx->max_e8 <= RQ_SCAN8_MAX_ROW_ERR;
+        if (int r = ensure_x8(idx, s)) return r;   // (may calibrate: the class's level is read again below)
+        use8 = idx->x8 && idx->x8_valid == idx->n && idx->max_e8 <= RQ_SCAN8_MAX_ROW_ERR && idx->scan8_level[kclass] < 2 &&
+               (B <= 64 || idx->scan8_level[kclass] == 0);
     }
     // Queries as ONE int8 image or as TWO (value + residual: the query's share of the bound vanishes, every corpus fragment
     // feeds two MFMAs).  Measured at 1M rows, fused loop: k = 10  132 us per batch with one image, 143-146 with two (the
@@ -585,7 +689,10 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
         const int big = wb == 1 ? 256 : (wb == 2 || wb == 3 ? 128 : 64);
         for (int left = B; left > 0;) {
             int qb = 64;
-            if (use8 && B > 64) qb = 128;                       // int8 image: passes of 128 queries
+            if (use8 && B > 64) {                               // int8 image: passes of 256 (rq_scan_wide.hip I8), 128 (rq_scan.hip I8 = 3) and 64 queries
+                if (idx->wide256_8 && big >= 256 && left > 128) qb = 256;
+                else if (left > 64 || !idx->wide256_8) qb = 128;
+            }
             else if (big >= 256 && left > 128) qb = 256;
             else if (big >= 128 && left > 64) qb = 128;
             if (npass == 1024) return set_err(RQ_EINVAL, "too many passes");
@@ -681,7 +788,8 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
         pa.q8lo = cx.ring_q8lo[nslot]; pa.qeps8s = cx.ring_qeps8s[nslot];
     }
     // one scan grid for every pass of the call (the tail reads nwg partition maxima per query): the widest pass decides
-    const int wg_cu = (qb0 > 64 && !use8) ? 1 : idx->wg_per_cu;   // every fp16 pass of more than 64 queries runs one 512-thread workgroup per CU
+    // every fp16 pass of more than 64 queries, and the int8 256-query pass, runs one 512-thread workgroup per CU
+    const int wg_cu = (qb0 > 64 && (!use8 || qb0 == 256)) ? 1 : idx->wg_per_cu;
     const int grid = (int)std::min<int64_t>(std::min<int64_t>(nquads, RQ_WGMAX_STRIDE), (int64_t)idx->cu_count * wg_cu);
     if (!exact) {
         // non-temporal loads only for shards that cannot stay in the 256 MiB Infinity Cache between two scans
@@ -702,7 +810,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             a.wgmax = w.wgmax + (size_t)q0 * RQ_WGMAX_STRIDE;
             a.wgmax_stride = RQ_WGMAX_STRIDE;
             if (use8) {
-                a.i8 = qb == 128 ? 3 : (split8 ? 2 : 1); a.qlo = q8lo; a.x = idx->x8; a.row_scale = metric == RQ_METRIC_IP ? idx->scale8_ip : idx->scale8_cos;
+                a.i8 = qb == 256 ? 4 : (qb == 128 ? 3 : (split8 ? 2 : 1)); a.qlo = q8lo; a.x = idx->x8; a.row_scale = metric == RQ_METRIC_IP ? idx->scale8_ip : idx->scale8_cos;
                 a.qh = (const _Float16*)(q8 + (size_t)q0 * RQ_DPAD); a.qscale = qscale8 + q0;
             }
             const bool prof = idx->profile == 1 && idx->ev_used < 16384 && (idx->scan_seq++ % (uint64_t)idx->profile_stride) == 0;
@@ -731,6 +839,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
                 none.nbins = nbins; none.m = none.k = 1; none.thr_mult = 2.25f; none.thr_slack = 0.f;
                 HIPCHK(rq_scan_tail_launch(a, none, 0, pa, nt, grid, idx->epi, s, e0, e1));
             } else if (fused) HIPCHK(rq_scan_launch(a, 3, 1, 2, 4, nt, grid, idx->epi, s, e0, e1));
+            else if (use8 && qb == 256) HIPCHK(rq_scan_wide_launch(a, idx->wide256_8, 256, nt, grid, s, e0, e1));   // 256 queries over the int8 image
             else if (use8) HIPCHK(rq_scan_launch(a, 3, 1, 2, 4, nt, grid, 1, s, e0, e1));   // 64 queries, or 128 (a.i8 = 3)
             else if (qb == 256) HIPCHK(rq_scan_wide_launch(a, idx->wide256, 256, nt, grid, s, e0, e1));
             else if (qb == 128 && idx->wide_batch == 2) HIPCHK(rq_scan_launch(a, 3, 4, 1, 8, nt, grid, 0, s, e0, e1));   // round 1's 8-wave pass
@@ -756,6 +865,8 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             ta.m = (int)std::min<int64_t>(k, idx->n); ta.metric = metric; ta.k = k;
             ta.eps = use8 ? scan8_eps(idx) : scan_eps(idx, metric);
             ta.qeps = use8 ? (split8 ? qeps8s : qeps8) : nullptr;
+            ta.binerr = use8 && idx->bin_bound ? idx->binerr8 : nullptr;
+            ta.eps_rows_max = use8 ? (float)idx->max_e8 : 0.f;
             // int8 scan: T = P - bound - slack.  The slack covers how far the k-th EXACT score may sit below P (= a k-th largest
             // APPROXIMATE score, biased upward by the errors of the rows that won); it is (thr_mult8 - 1) x the larger of the
             // query's own bound and the one-image bound of a typical query -- also when the queries are split (their bound is
@@ -844,6 +955,29 @@ extern "C" int rq_search_hint_next_device(rq_index* idx, const float* d_next_que
     const bool usable = d_next_queries && B >= 1 && B <= 64 && idx->use_hint && idx->pipeline == 2;
     c.hint_q = usable ? d_next_queries : nullptr;
     c.hint_B = usable ? B : 0;
+    return RQ_OK;
+}
+
+extern "C" int rq_search_train_device(rq_index* idx, int n_batches, const float* const* d_queries, int B, int k, int metric,
+                                      float* const* d_scores, int64_t* const* d_rows, uint64_t* const* d_keys, int* const* d_status,
+                                      void* const* streams, int n_streams) {
+    if (!idx || n_batches < 0 || !d_queries || !d_scores || !d_rows || !d_status || !streams || n_streams < 1 || n_streams > 8)
+        return set_err(RQ_EINVAL, "bad train arguments");
+    if (!idx->shards.empty()) return set_err(RQ_EUNSUPPORTED, "device-pointer searches on a multi-device index: use rq_search (host buffers), or one index per device");
+    for (int i = 0; i < n_batches; ++i) {
+        if (int r = check_search_args(idx, d_queries[i], B, k, metric, d_scores[i], d_rows[i])) return r;
+        if (!d_status[i]) return set_err(RQ_EINVAL, "d_status is required");
+    }
+    RQ_ON_DEVICE(idx);
+    for (int i = 0; i < n_batches; ++i) {
+        hipStream_t s = (hipStream_t)streams[i % n_streams];
+        if (const float* nxt = d_queries[i + n_streams])
+            if (int r = rq_search_hint_next_device(idx, nxt, B, s)) return r;
+        idx->t.searches++;
+        idx->t.queries += B;
+        if (int r = run_pipeline(idx, d_queries[i], B, k, metric, nb_default(idx, k), d_scores[i], d_rows[i], d_keys ? d_keys[i] : nullptr, d_status[i], s, true))
+            return r;
+    }
     return RQ_OK;
 }
 
@@ -1096,6 +1230,17 @@ extern "C" int64_t rq_debug_pooled(rq_index* idx, void* stream, int query, float
     std::vector<uint32_t> raw((size_t)n);
     HIPCHK(hipMemcpy2D(raw.data(), sizeof(uint32_t), w.bins + (size_t)query * w.bins_stride, sizeof(uint2), sizeof(uint32_t), (size_t)n, hipMemcpyDeviceToHost));
     for (int64_t i = 0; i < n; ++i) out[i] = rq_rec_m1(raw[(size_t)i]);
+    return n;
+}
+
+// ---- test hook: the int8 image's worst row error per bin (what the tail lifts its threshold by) -------------
+extern "C" int64_t rq_debug_bin_err(rq_index* idx, float* out, int64_t max_bins) {
+    if (!idx || !out || !idx->shards.empty()) return set_err(RQ_EINVAL, "bad arguments");
+    RQ_ON_DEVICE(idx);
+    if (!idx->x8 || !idx->binerr8 || idx->x8_valid != idx->n) return set_err(RQ_EINVAL, "the int8 image is not built (run a search with the int8 scan first)");
+    const int64_t n = std::min((idx->n + 63) / 64, max_bins);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, idx->binerr8, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     return n;
 }
 

@@ -109,6 +109,7 @@ struct rq_index {
     signed char* x8 = nullptr;
     float* scale8_cos = nullptr;   // [cap] s_row / ||row||, pad rows NaN
     float* scale8_ip = nullptr;    // [cap] s_row
+    float* binerr8 = nullptr;      // [cap / 64] worst row's relative quantisation error of every bin (fp32, rounded up)
     unsigned long long* d_stat8 = nullptr;   // device: bits of the largest relative quantisation error of a row
     int64_t x8_valid = 0;
     double max_e8 = 0.0;           // host copy of that maximum over rows [0, x8_valid)
@@ -120,11 +121,15 @@ struct rq_index {
     int scan8_level[2] = {0, 1};
     int64_t scan8_checked[2] = {0, 0}, scan8_repaired[2] = {0, 0};
     int64_t scan8_used = 0;        // searches that scanned the int8 image
+    bool calibrating = false;      // scan8_calibrate is running its sample searches
+    int64_t calib_rows = 0;        // rows of the shard when the ladder's start levels were last measured (0 = not yet)
+    float calib_ms[2][3] = {{0, 0, 0}, {0, 0, 0}};   // per class, per rung (one image / two images / fp16): ms of the 64-query sample search
+    int calib_unc[2][3] = {{0, 0, 0}, {0, 0, 0}};    // ... and its uncertified queries
     bool last_use8 = false;        // the caller's last search scanned the int8 image (what rq_search_fixup_device's repairs are counted against)
     int64_t hints_used = 0;        // rq_search_hint_next_device: searches that skipped their preparation launch
     uint64_t scan_seq = 0;         // scan launches seen while profile = 1 (every profile_stride-th one is timed)
     // options
-    int ring = 3, prefetch = 1, kstage = 2, wide_batch = 1, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, profile_stride = 1, scan_nostore = 0, fast_tail = 1, pipeline = 0, tail_stop = 0, poison_cand = 0, wide128 = 0, wide256 = 11, epi = 1, use_hint = 1, profile_legacy = 0, scan8 = 1, tail_local = 1, scan8_split = -1, wide8 = 1;
+    int ring = 3, prefetch = 1, kstage = 2, wide_batch = 1, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, profile_stride = 1, scan_nostore = 0, fast_tail = 1, pipeline = 0, tail_stop = 0, poison_cand = 0, wide128 = 0, wide256 = 11, epi = 1, use_hint = 1, profile_legacy = 0, scan8 = 1, tail_local = 1, scan8_split = -1, wide8 = 1, wide256_8 = 20, bin_bound = 1;
     double thr_mult8 = 1.25;       // int8 scan: threshold = P - thr_mult8 * bound (rq_tail_body.h)
     double eps = -1.0;
     std::map<hipStream_t, StreamCtx> ctx;

@@ -62,8 +62,9 @@ hipError_t rq_prep_queries_launch(const RqPrepArgs& a, hipStream_t stream);   //
 // int8 image of rows [row_begin, row_end) for the int8 scan: x8[row][768] = round(x / s_row), s_row = max|x_i| / 127;
 // scale_cos[row] = s_row / ||row|| (0 for a zero row), scale_ip[row] = s_row; stat[0] (device, double bits, running
 // maximum) = largest ||x - s x8|| / ||x|| of a row (+inf for a row with non-finite elements)
+// binerr[row / 64] (device, fp32 bits, running maximum, zero before the first call) = the same figure for the worst row of every bin
 hipError_t rq_quant_rows_launch(const void* x, const double* norm64, int64_t row_begin, int64_t row_end, signed char* x8,
-                                float* scale_cos, float* scale_ip, unsigned long long* stat, hipStream_t stream);
+                                float* scale_cos, float* scale_ip, unsigned long long* stat, float* binerr, hipStream_t stream);
 
 // Pass 2: per query, the m best bins of bins[q][0..nbins) as sorted keys (score desc, bin asc); 0-padded.
 hipError_t rq_select_bins_launch(const uint2* bins, int64_t bins_stride, int64_t nbins, int B, int m,
@@ -124,6 +125,8 @@ struct RqTailArgs {
     int* rowcount; int* done; int* ovf;            // [B] each, zero before the launch, reset by the kernel
     float* out_scores; int64_t* out_rows; uint64_t* out_keys; int* out_status;
     const float* qeps;                             // per query error share e_q (int8 scan): bound = e_q (1 + eps) + eps; null = eps alone
+    const float* binerr;                           // int8 scan: worst row error of every bin (rq_quant_rows_kernel), or null.  A bin is tested against
+    float eps_rows_max;                            //   T + (1 + e_q) (eps_rows_max - binerr[bin]): its own rows' bound instead of the shard's worst row
     int local_topk;                                // 1: a workgroup with more than k row jobs publishes only its own k best keys (rq_tail_body.h)
     float thr_mult;                                // threshold T = P - bound - (thr_mult - 1) * max(bound, thr_slack): 2.25 always
     float thr_slack;                               //   certifies; less = fewer candidates, the rare query is repaired (rq_tail_body.h)

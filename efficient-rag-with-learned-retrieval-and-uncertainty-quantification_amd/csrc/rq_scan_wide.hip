@@ -17,6 +17,11 @@
 //     stages (48 KiB per CU) in flight like the 64-query kernel does with its two workgroups per CU;
 //   * QG = 2: a wave keeps 2 x 16 queries in registers (192 VGPRs, one wave per SIMD) and every fragment it reads feeds
 //     two MFMAs -- half the LDS reads per query of the 8-wave form.
+//   * I8 (round 3): the same schedule over the int8 image of the shard (rq_scan.hip I8) for 256 queries per
+//     pass: a stage is still 24 KiB but holds TWO tiles (32 rows of 768 B), a quad is two stages, the ring of 4 slots two
+//     quads (slot = 2 * (quad parity) + stage); v_mfma_i32_16x16x64_i8, 12 k-steps per tile, so a stage is 24 fragments in
+//     both forms and the read-ahead stream is the same code.  The query fragments of 2 groups take 96 VGPRs instead of 192:
+//     the reads run 12 fragments ahead where the fp16 256-query form has registers for 2.
 // Replaces the arithmetic of reference rag_uq/streaming_index.py:355-359 (collection.query), like rq_scan.hip.
 #include <hip/hip_ext.h>
 
@@ -41,12 +46,21 @@ __host__ __device__ static constexpr int rqw_sq(int QW, int QG) { return QW * QG
 // EPI: 1 = the selection keeps the row position in the 6 low mantissa bits of the score (v_med3 inserts, 6 VALU per score),
 //      0 = rq_scan.hip's compare/select form (14 VALU per score).
 // DBG (timing experiments only, results invalid): 1 = no selection epilogue, 2 = no LDS fragment reads, 3 = no MFMAs
-template <bool NT, int D, int QW, int QG, int EPI, int DBG = 0, int PRIO = 0>
+template <bool NT, int D, int QW, int QG, int EPI, int DBG = 0, int PRIO = 0, int I8 = 0>
 __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, const int G) {
     static_assert(D >= 2 && D <= 12 && 24 % D == 0, "prefetch distance");
     static_assert(QW == 4 || QW == 8, "waves per workgroup");
     static_assert(QG == 1 || QG == 2, "query groups per wave");
-    constexpr int STAGE_BYTES = 24576;             // 16 rows x 1536 B
+    static_assert(I8 == 0 || (EPI == 1 && DBG == 0 && PRIO != 2), "int8 form: med3 selection only");
+    constexpr int ROWB = I8 ? RQ_DPAD : RQ_DPAD * 2;   // bytes per corpus row
+    constexpr int KS = I8 ? 12 : 24;               // k-steps = LDS fragments per tile
+    constexpr int TPS = I8 ? 2 : 1;                // tiles per stage
+    constexpr int SPQ = 4 / TPS;                   // stages per quad
+    constexpr int FQ = 4 * KS;                     // fragments per quad
+    constexpr int CH = ROWB / 16;                  // 16-byte chunks per row
+    constexpr int TILE_BYTES = 16 * ROWB;
+    constexpr int STAGE_BYTES = 24576;             // 16 rows x 1536 B, or 32 rows x 768 B
+    static_assert(FQ % D == 0, "the fragment ring must close over a quad");
     constexpr int DPW = 24 / QW;                   // LDS-DMA wave-instructions (1 KiB each) per wave per stage
     constexpr int VM_KEEP = DPW;                   // at an acquire, the wave's pieces of the NEXT stage may stay in flight
     constexpr unsigned AUX = NT ? 2u : 0u;
@@ -57,27 +71,28 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
     const int kg = lane >> 4;          // k-group of the MFMA operand / row group of the result
     const int r16 = lane & 15;         // corpus row inside the tile (A operand), query inside the group (D)
 
-    // per-lane DMA source offsets: LDS chunk p = 64*j + lane of a stage holds row r = p / 96, source chunk (p % 96) ^ r
+    // per-lane DMA source offsets: LDS chunk p = 64*j + lane of a stage holds row r = p / CH, source chunk (p % CH) ^ (r & 15)
     unsigned voff[DPW];
 #pragma unroll
     for (int i = 0; i < DPW; ++i) {
         const int p = 64 * (wave * DPW + i) + lane;
-        const int r = p / 96, cp = p % 96;
-        voff[i] = (unsigned)(r * (RQ_DPAD * 2) + ((cp ^ r) << 4));
+        const int r = p / CH, cp = p % CH;
+        voff[i] = (unsigned)(r * ROWB + ((cp ^ (r & 15)) << 4));
     }
     // per-lane LDS read offset of k-step s: (rbase0 ^ ((s & 3) << 6)) + ((s & ~3) << 6)   (see rq_scan.hip)
-    const unsigned rbase0 = (unsigned)(r16 * 1536 + ((kg ^ (r16 & 3)) << 4) + ((r16 >> 2) << 6));
+    static_assert(ROWB % 256 == 0, "row pitch must keep bits 6..7 free");
+    const unsigned rbase0 = (unsigned)(r16 * ROWB + ((kg ^ (r16 & 3)) << 4) + ((r16 >> 2) << 6));
 
     const int q_lo = (int)((int64_t)b * a.nquads / G);
     const int nloc = (int)((int64_t)(b + 1) * a.nquads / G) - q_lo;
-    const int nst = nloc * 4;          // stages = tiles of this workgroup's quads
+    const int nst = nloc * SPQ;        // stages of this workgroup's quads
     const char* xb = (const char*)a.x;
     char* norm_lds = rq_smem_w + 4 * STAGE_BYTES;                // [2 parities][64 row scales]
     uint2* const stg = (uint2*)(norm_lds + 512);                 // [16 * QW * QG queries][SQ] finished records
 
-    // stage gs = tile (gs & 3) of local quad (gs >> 2) -> ring slot (gs & 3).  Stages are issued strictly in order, so the
+    // stage gs = stage (gs % SPQ) of local quad (gs / SPQ) -> ring slot (gs & 3).  Stages are issued strictly in order, so the
     // source addresses are two running (wave-uniform) pointers instead of 64-bit multiplications per stage.
-    const char* gnext = xb + (int64_t)q_lo * (RQ_QUAD_ROWS * RQ_DPAD * 2);           // corpus bytes of the next stage
+    const char* gnext = xb + (int64_t)q_lo * (RQ_QUAD_ROWS * ROWB);                  // corpus bytes of the next stage
     const float* nsnext = a.row_scale + (int64_t)q_lo * RQ_QUAD_ROWS + lane;       // row scales of the next quad
     auto issue = [&](int gs) {
         const int t = gs & 3;
@@ -86,8 +101,8 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
         for (int i = 0; i < DPW; ++i)
             __builtin_amdgcn_global_load_lds((glb_ptr_w)(gnext + voff[i]), (lds_ptr_w)(l + i * 1024), 16, 0, AUX);
         gnext += STAGE_BYTES;
-        if (t == 0) {   // row scales of the quad (256 B); visible to all waves after wave 0's wait + a barrier
-            if (wave == 0) __builtin_amdgcn_global_load_lds((glb_ptr_w)nsnext, (lds_ptr_w)(norm_lds + (((gs >> 2) & 1) << 8)), 4, 0, 0);
+        if ((gs & (SPQ - 1)) == 0) {   // row scales of the quad (256 B); visible to all waves after wave 0's wait + a barrier
+            if (wave == 0) __builtin_amdgcn_global_load_lds((glb_ptr_w)nsnext, (lds_ptr_w)(norm_lds + (((gs / SPQ) & 1) << 8)), 4, 0, 0);
             nsnext += RQ_QUAD_ROWS;
         }
     };
@@ -107,15 +122,18 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
 #pragma unroll
     for (int g = 0; g < QG; ++g) wmax[g] = NEG_INF;
 
-    // query fragments: B[k = 8*kg + j][col = r16] of k-step s == qh[16*(QG*wave + g) + r16][32*s + 8*kg + j]
-    rq_half8 qf[QG][24];
+    // query fragments: fp16  B[k = 8*kg + j][col = r16] of k-step s == qh[16*(QG*wave + g) + r16][32*s + 8*kg + j]
+    //                  int8  B[k = 16*kg + j][col = r16] of k-step s == q8[16*(QG*wave + g) + r16][64*s + 16*kg + j]   (16 bytes per fragment either way)
+    rq_half8 qf[QG][KS];
+    float qsc[QG];      // int8: s_q / |q| of this lane's query (rq_prep_body), applied once per quad
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
-        const rq_half8* qsrc = (const rq_half8*)(a.qh + (size_t)(16 * (QG * wave + g) + r16) * RQ_DPAD + 8 * kg);
+        const rq_half8* qsrc = (const rq_half8*)((const char*)a.qh + (size_t)(16 * (QG * wave + g) + r16) * ROWB + 16 * kg);
 #pragma unroll
-        for (int s = 0; s < 24; ++s) qf[g][s] = qsrc[4 * s];
+        for (int s = 0; s < KS; ++s) qf[g][s] = qsrc[4 * s];
 #pragma unroll
-        for (int s = 0; s < 24; ++s) asm volatile("" : "+v"(qf[g][s]));   // ordinary loads retired before the main loop
+        for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qf[g][s]));   // ordinary loads retired before the main loop
+        qsc[g] = I8 ? a.qscale[16 * (QG * wave + g) + r16] : 1.f;
     }
 
     // PRIO == 3: the fragment reads are asm (ds_read_b128 with immediate offsets from 8 per-lane base addresses) and every
@@ -123,14 +141,29 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
     // compiler's own schedule drains the whole LDS queue (lgkmcnt(0)) every few fragments, which exposes the latency of the
     // read it has just issued.  LDS operations return in order, so other LDS instructions (the compiler's: row scales,
     // record staging, shuffles) between the asm reads can only make a counted wait stricter, never too lax.
-    unsigned abase[2][4];
+    unsigned abase[2][4];   // [ring half: slots 0-1 / 2-3][s & 3]
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         abase[0][m] = (unsigned)(size_t)(lds_ptr_w)rq_smem_w + (rbase0 ^ (unsigned)(m << 6));
         abase[1][m] = abase[0][m] + 2 * STAGE_BYTES;
     }
-    auto frag = [&](int t, int s) -> rq_half8 {
+    // fp16: tile t of a quad sits in slot t (static).  int8: tile t sits in slot 2 * parity + t / 2 at offset (t & 1) * TILE_BYTES,
+    // parity = that quad's (lq & 1): `bc` = per-lane bases of the quad being multiplied, `bn` = of the quad after it.
+    unsigned bc[4], bn[4];
+    auto set_bases = [&](int lq) {
+        const unsigned cur = (unsigned)((lq & 1) * 2 * STAGE_BYTES), nxt = (unsigned)(((lq + 1) & 1) * 2 * STAGE_BYTES);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { bc[m] = abase[0][m] + cur; bn[m] = abase[0][m] + nxt; }
+    };
+    auto frag = [&](int t, int s, bool next_quad) -> rq_half8 {
         if (DBG == 2) { rq_half8 z; asm volatile("" : "=v"(z)); return z; }
+        if (I8) {
+            rq_half8 v;
+            const unsigned base = next_quad ? bn[s & 3] : bc[s & 3];
+            if (PRIO == 3) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(base), "n"((t >> 1) * STAGE_BYTES + (t & 1) * TILE_BYTES + ((s & ~3) << 6)));
+            else v = *(const rq_half8*)((const char*)(__attribute__((address_space(3))) const char*)(size_t)base + (t >> 1) * STAGE_BYTES + (t & 1) * TILE_BYTES + ((s & ~3) << 6));
+            return v;
+        }
         if (PRIO == 3) {
             rq_half8 v;
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(abase[t >> 1][s & 3]), "n"((t & 1) * STAGE_BYTES + ((s & ~3) << 6)));
@@ -151,13 +184,15 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
     // static priority for the second-dispatched half of an 8-wave workgroup (MI355X_MICROARCH.md, two waves per SIMD, item 4)
     if (PRIO == 1 && QW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
     rq_half8 av[D];   // fragment ring: fragment f of the quad lives in av[f % D]
+    if (I8) set_bases(0);
     acquire(0);
 #pragma unroll
-    for (int f = 0; f < D; ++f) av[f] = frag(0, f);
+    for (int f = 0; f < D; ++f) av[f] = frag(f / KS, f % KS, false);
 
     for (int lq = 0; lq < nloc; ++lq) {
         const int quad = q_lo + lq;
         const bool more = lq + 1 < nloc;
+        if (I8) set_bases(lq);
         float m1[QG], m2[QG], m3[QG];   // the three largest approximate scores of the lane's 16 rows, per query group
         uint32_t ap[QG];                // rows (0..63) of the largest [7:0] and second largest [15:8]
 #pragma unroll
@@ -168,6 +203,7 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
         // quad), so that of the two waves that share a SIMD one is in its VALU epilogue while the other feeds the matrix
         // core instead of both doing the same thing at the same time (MI355X_MICROARCH.md, two waves per SIMD, item 9)
         rq_float4 acc2[2][QG];
+        rq_int4 iacc2[2][QG];
         const bool late = PRIO == 2 && QW == 8 && wave >= 4;
         auto select_tile = [&](int t) {
             const rq_float4 nv = *(const rq_float4*)(nrow + t * 64);
@@ -181,45 +217,50 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
 #pragma clang loop unroll(full)
         for (int t = 0; t < 4; ++t)
 #pragma clang loop unroll(full)
-        for (int s = 0; s < 24; ++s) {
-            const int f = t * 24 + s;
+        for (int s = 0; s < KS; ++s) {
+            const int f = t * KS + s;
             const rq_half8 cur = av[f % D];
             // the read pointer: fragment f + D, D fragments ahead, crossing stage (and quad) boundaries
             {
                 const int r = f + D;
-                if (r < 96) {
-                    if (r % 24 == 0) acquire(lq * 4 + r / 24);
-                    av[f % D] = frag(r / 24, r % 24);
+                if (r < FQ) {
+                    if (r % 24 == 0) acquire(lq * SPQ + r / 24);
+                    av[f % D] = frag(r / KS, r % KS, false);
                 } else {
                     // the next quad's first fragments; after the workgroup's last quad the reads still run (unconditional
-                    // code, no copies) on bytes nobody uses: nothing is in flight into slot 0 any more
-                    if (r == 96 && more) acquire(lq * 4 + 4);
-                    av[f % D] = frag(0, r - 96);
+                    // code, no copies) on bytes nobody uses: nothing is in flight into that slot any more
+                    if (r == FQ && more) acquire(lq * SPQ + SPQ);
+                    av[f % D] = frag((r - FQ) / KS, (r - FQ) % KS, true);
                 }
             }
             rq_half8 curw = cur;
             if (PRIO == 3) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(curw) : "n"(D));   // fragment f has landed; f+1 .. f+D may be in flight
             rq_float4 (&acc)[QG] = acc2[t & 1];
+            rq_int4 (&iacc)[QG] = iacc2[t & 1];
             if (s == 0) {
 #pragma unroll
-                for (int g = 0; g < QG; ++g) acc[g] = rq_float4{0.f, 0.f, 0.f, 0.f};
+                for (int g = 0; g < QG; ++g) { acc[g] = rq_float4{0.f, 0.f, 0.f, 0.f}; iacc[g] = rq_int4{0, 0, 0, 0}; }
             }
             if (DBG == 3) {
 #pragma unroll
                 for (int g = 0; g < QG; ++g) asm volatile("" : "+v"(acc[g]) : "v"(curw), "v"(qf[g][s]));
+            } else if (I8) {
+#pragma unroll
+                for (int g = 0; g < QG; ++g)
+                    iacc[g] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(rq_int4, curw), __builtin_bit_cast(rq_int4, qf[g][s]), iacc[g], 0, 0, 0);
             } else {
 #pragma unroll
             for (int g = 0; g < QG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(curw, qf[g][s], acc[g], 0, 0, 0);
             }
             if (PRIO == 2 && EPI == 1 && DBG == 0) {
                 if (s == 11 && t >= 1) { if (late) select_tile(t - 1); }
-                if (s == 23) { if (!late || t == 3) select_tile(t); }
+                if (s == KS - 1) { if (!late || t == 3) select_tile(t); }
             }
-            if (s == 23 && DBG == 1) {
+            if (s == KS - 1 && DBG == 1) {
 #pragma unroll
                 for (int g = 0; g < QG; ++g) m1[g] = fmaxf(m1[g], fmaxf(fmaxf(acc[g][0], acc[g][1]), fmaxf(acc[g][2], acc[g][3])));
             }
-            if (s == 23 && DBG != 1 && EPI == 1 && PRIO != 2) {
+            if (s == KS - 1 && DBG != 1 && EPI == 1 && PRIO != 2) {
                 // Tile epilogue, D[row = 4*kg + i][query = r16].  score = acc * row scale, clamped to the finite range (an
                 // infinite score stays the largest, NaN becomes the smallest); its 6 low mantissa bits are then REPLACED by
                 // the row's position in the quad (bits 4..5 tile, 0..1 register; the lane's row group 4*kg is OR-ed in
@@ -227,15 +268,17 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
                 // data-dependent code.  The perturbation (< 64 ulp, 7.6e-6 relative) is part of the scan's error bound
                 // eps; every field of the record written below stays an UPPER bound of the unperturbed score.
                 // Rows beyond the shard's end carry a NaN row scale (rq_api.hip) and therefore sort last.
+                // int8: |sum| <= 768 * 127 * 127 < 2^24, the conversion to fp32 is exact; the query's scale follows once per quad.
                 const rq_float4 nv = *(const rq_float4*)(nrow + t * 64);
 #pragma unroll
                 for (int g = 0; g < QG; ++g)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        rq_insert3(m1[g], m2[g], m3[g], rq_pos_score(acc[g][i] * nv[i], (uint32_t)(t * 16 + i)));
+                        const float raw = I8 ? (float)iacc[g][i] : acc[g][i];
+                        rq_insert3(m1[g], m2[g], m3[g], rq_pos_score(raw * nv[i], (uint32_t)(t * 16 + i)));
                     }
             }
-            if (s == 23 && DBG != 1 && EPI == 0) {
+            if (s == KS - 1 && DBG != 1 && EPI == 0) {
                 // tile epilogue: D[row = 4*kg + i][query = r16]
                 const rq_float4 nv = *(const rq_float4*)(nrow + t * 64);
                 const int64_t row0 = (int64_t)quad * RQ_QUAD_ROWS + t * RQ_TILE_ROWS + 4 * kg;
@@ -258,11 +301,14 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
         if (EPI == 1) {
 #pragma unroll
             for (int g = 0; g < QG; ++g) {
-                // positions become complete (row group of the lane), then the four lanes that share the query merge their
+                // (int8: the query's positive scale first -- the order is unchanged and the positions ride through it;) positions become
+                // complete (row group of the lane), then the four lanes that share the query merge their
                 // sorted triples: the other lane's three values are inserted one by one; all four lanes end up equal
                 const uint32_t kgb = (uint32_t)kg << 2;
-                float x1 = __uint_as_float(__float_as_uint(m1[g]) | kgb), x2 = __uint_as_float(__float_as_uint(m2[g]) | kgb),
-                      x3 = __uint_as_float(__float_as_uint(m3[g]) | kgb);
+                float y1 = m1[g], y2 = m2[g], y3 = m3[g];
+                if (I8) { y1 = rq_scale_pos(y1, qsc[g]); y2 = rq_scale_pos(y2, qsc[g]); y3 = rq_scale_pos(y3, qsc[g]); }
+                float x1 = __uint_as_float(__float_as_uint(y1) | kgb), x2 = __uint_as_float(__float_as_uint(y2) | kgb),
+                      x3 = __uint_as_float(__float_as_uint(y3) | kgb);
 #pragma unroll
                 for (int off = 16; off <= 32; off <<= 1) {
                     const float o1 = __shfl_xor(x1, off, 64), o2 = __shfl_xor(x2, off, 64), o3 = __shfl_xor(x3, off, 64);
@@ -312,12 +358,12 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
 
 static constexpr size_t rq_scanw_lds_bytes(int QW, int QG) { return (size_t)4 * 24576 + 512 + (size_t)16 * QW * QG * rqw_sq(QW, QG) * 8; }
 
-template <bool NT, int D, int OCC, int QW, int QG, int EPI, int DBG, int PRIO>
+template <bool NT, int D, int OCC, int QW, int QG, int EPI, int DBG, int PRIO, int I8>
 __global__ __launch_bounds__(64 * QW, OCC) void rq_scanw_kernel(RqScanArgs a) {
-    rq_scanw_body<NT, D, QW, QG, EPI, DBG, PRIO>(a, (int)blockIdx.x, (int)gridDim.x);
+    rq_scanw_body<NT, D, QW, QG, EPI, DBG, PRIO, I8>(a, (int)blockIdx.x, (int)gridDim.x);
 }
 
-template <bool NT, int D, int OCC, int QW, int QG, int EPI = 0, int DBG = 0, int PRIO = 0>
+template <bool NT, int D, int OCC, int QW, int QG, int EPI = 0, int DBG = 0, int PRIO = 0, int I8 = 0>
 static hipError_t rq_scanw_launch_t(const RqScanArgs& a, int grid, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
     constexpr size_t lds = rq_scanw_lds_bytes(QW, QG);
     static_assert(lds <= 160 * 1024, "LDS of one workgroup");
@@ -326,12 +372,12 @@ static hipError_t rq_scanw_launch_t(const RqScanArgs& a, int grid, hipStream_t s
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (!((attr_done >> (dev & 63)) & 1ull)) {
-        e = hipFuncSetAttribute((const void*)rq_scanw_kernel<NT, D, OCC, QW, QG, EPI, DBG, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipFuncSetAttribute((const void*)rq_scanw_kernel<NT, D, OCC, QW, QG, EPI, DBG, PRIO, I8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done |= 1ull << (dev & 63);
     }
-    if (e0 && e1) hipExtLaunchKernelGGL((rq_scanw_kernel<NT, D, OCC, QW, QG, EPI, DBG, PRIO>), dim3(grid), dim3(64 * QW), (uint32_t)lds, stream, e0, e1, 0, a);
-    else hipLaunchKernelGGL((rq_scanw_kernel<NT, D, OCC, QW, QG, EPI, DBG, PRIO>), dim3(grid), dim3(64 * QW), lds, stream, a);
+    if (e0 && e1) hipExtLaunchKernelGGL((rq_scanw_kernel<NT, D, OCC, QW, QG, EPI, DBG, PRIO, I8>), dim3(grid), dim3(64 * QW), (uint32_t)lds, stream, e0, e1, 0, a);
+    else hipLaunchKernelGGL((rq_scanw_kernel<NT, D, OCC, QW, QG, EPI, DBG, PRIO, I8>), dim3(grid), dim3(64 * QW), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -357,6 +403,10 @@ hipError_t rq_scan_wide_launch(const RqScanArgs& a, int variant, int queries, bo
     RQW_CASE(4, 4, 2, 8, 1, 0) RQW_CASE(5, 4, 1, 4, 2, 1)
     RQW_CASE(6, 12, 2, 8, 1, 1, 0, 2) RQW_CASE(7, 12, 2, 8, 1, 1, 0, 1)
     RQW_CASE(8, 12, 2, 8, 1, 1, 0, 3) RQW_CASE(11, 2, 2, 8, 2, 1, 0, 3)
+    // int8 image (a.i8 = 4): 20  256 queries, reads 12 ahead, asm reads + counted waits   <- default ("wide256_8")
+    //                        21  as 20, reads 6 ahead;  22  as 20, compiler-scheduled reads;  23  128 queries (8 waves x 1 group), reads 12 ahead
+    RQW_CASE(20, 12, 2, 8, 2, 1, 0, 3, 1) RQW_CASE(21, 6, 2, 8, 2, 1, 0, 3, 1) RQW_CASE(22, 12, 2, 8, 2, 1, 0, 0, 1)
+    RQW_CASE(23, 12, 2, 8, 1, 1, 0, 3, 1)
     RQW_CASE(90, 4, 2, 8, 1, 0, 1) RQW_CASE(91, 4, 2, 8, 1, 0, 2) RQW_CASE(92, 4, 2, 8, 1, 0, 3)
     RQW_CASE(93, 12, 2, 8, 1, 1, 1) RQW_CASE(94, 12, 2, 8, 1, 1, 2) RQW_CASE(95, 12, 2, 8, 1, 1, 3)
 #undef RQW_CASE

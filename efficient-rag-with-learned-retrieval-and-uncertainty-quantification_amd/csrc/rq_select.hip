@@ -166,7 +166,8 @@ hipError_t rq_prep_queries_launch(const RqPrepArgs& a, hipStream_t stream) {
 // worst row is what the int8 scan's certificate rests on, so it is summed in fp64 from the values the scan will use.
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rq_quant_rows_kernel(const char* x, const double* norm64, int64_t row_begin, int64_t row_end,
-                                                            signed char* x8, float* scale_cos, float* scale_ip, unsigned long long* stat) {
+                                                            signed char* x8, float* scale_cos, float* scale_ip, unsigned long long* stat,
+                                                            unsigned* binerr) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
@@ -210,17 +211,21 @@ __global__ __launch_bounds__(256) void rq_quant_rows_kernel(const char* x, const
             scale_cos[row] = live ? (float)((double)sr / nrm) : 0.f;
             scale_ip[row] = sr;
         }
-        if (bad) mx = (double)__builtin_huge_valf();
-        else if (live) mx = fmax(mx, sqrt(err) / nrm);
+        const double e = bad ? (double)__builtin_huge_valf() : (live ? sqrt(err) / nrm : 0.0);
+        mx = fmax(mx, e);
+        // the worst row of every BIN (64 rows): the tail tests a bin against a threshold that is as much higher as this bin's rows
+        // quantise better than the shard's worst row (rq_tail_body.h).  Non-negative floats order like their bit patterns; the
+        // value is rounded UP to fp32.
+        if (lane == 0 && e > 0.0) atomicMax(&binerr[row >> 6], __float_as_uint(__double2float_ru(e)));
     }
     if (lane == 0 && mx > 0.0) atomicMax(&stat[0], (unsigned long long)__double_as_longlong(mx));
 }
 hipError_t rq_quant_rows_launch(const void* x, const double* norm64, int64_t row_begin, int64_t row_end, signed char* x8,
-                                float* scale_cos, float* scale_ip, unsigned long long* stat, hipStream_t stream) {
+                                float* scale_cos, float* scale_ip, unsigned long long* stat, float* binerr, hipStream_t stream) {
     if (row_end <= row_begin) return hipSuccess;
     const int64_t rows = row_end - row_begin;
     const int grid = (int)((rows + 3) / 4 < 8192 ? (rows + 3) / 4 : 8192);
-    hipLaunchKernelGGL(rq_quant_rows_kernel, dim3(grid), dim3(256), 0, stream, (const char*)x, norm64, row_begin, row_end, x8, scale_cos, scale_ip, stat);
+    hipLaunchKernelGGL(rq_quant_rows_kernel, dim3(grid), dim3(256), 0, stream, (const char*)x, norm64, row_begin, row_end, x8, scale_cos, scale_ip, stat, (unsigned*)binerr);
     return hipGetLastError();
 }
 

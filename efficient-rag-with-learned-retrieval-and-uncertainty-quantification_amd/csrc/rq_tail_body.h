@@ -44,10 +44,12 @@ __device__ __forceinline__ void rq_tail_body(const RqTailArgs& a, const int chun
     const uint2* p = a.bins + (int64_t)q * a.bins_stride;
     const int64_t cbase = (int64_t)chunk * CHUNK + tid * 2;
     uint4 v4[NV];   // two records each
+    float2 be[NV];  // int8 scan: the two bins' worst row errors
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
         const int64_t i = cbase + (int64_t)u * 512;
         v4[u] = (i < a.bins_stride) ? *(const uint4*)(p + i) : make_uint4(0u, 0u, 0u, 0u);   // bins_stride is even
+        be[u] = (a.binerr && i < a.bins_stride) ? *(const float2*)(a.binerr + i) : make_float2(0.f, 0.f);
     }
     float qmine[3];
     {
@@ -108,12 +110,18 @@ __device__ __forceinline__ void rq_tail_body(const RqTailArgs& a, const int chun
     // ---- B. bins of this chunk that reach the threshold -> row jobs: the arg-max row alone when the bin's second
     //      largest score is below T, the two largest when only the third is, all 64 rows otherwise
     {
+        // int8 scan: |approx - exact| <= e_q + (1 + e_q) e_rows for the rows of a bin, e_rows <= the bin's worst row <= the shard's.  T was
+        // set with the shard's worst row; a bin whose rows quantise better is tested against Tb = T + (1 + e_q)(shard - bin): a row left
+        // out there has approx < Tb, hence exact < Tb + e_q + (1 + e_q) bin = T + eps_q -- the same certificate (rq_final_body).
+        const float lift = a.binerr ? (1.f + a.qeps[q]) * (a.metric == 0 ? 1.f : a.max_row_norm) * 0.9999f : 0.f;
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
             const uint32_t rx[2] = {v4[u].x, v4[u].z}, ry[2] = {v4[u].y, v4[u].w};
+            const float eb[2] = {be[u].x, be[u].y};
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int64_t i = cbase + (int64_t)u * 512 + e;
+                const float T = a.binerr ? thr_s + lift * fmaxf(a.eps_rows_max - eb[e] * 1.000001f, 0.f) : thr_s;
                 if (i < a.nbins && rq_rec_m1(rx[e]) >= T) {
                     const int h = atomicAdd(&nhit_s, 1);
                     if (h < RQ_TAIL_HITCAP) {

@@ -105,6 +105,17 @@ int rq_search_flush_device(rq_index* idx, void* stream);
  * 64 queries, another pipeline mode, a different pointer / B at the next call, a flush in between) is dropped and the
  * next call prepares its queries itself; results never depend on it.  B = 0 or NULL withdraws a pending hint. */
 int rq_search_hint_next_device(rq_index* idx, const float* d_next_queries, int B, void* stream);
+/* A TRAIN of searches enqueued by one call (serving loops, the multi-GPU bench: a 125 k-row shard answers a 64-query batch in
+ * ~25 us, which a host loop that crosses the language boundary twice per batch cannot feed): batch i = B queries at
+ * d_queries[i], searched exactly as rq_search_device(idx, d_queries[i], B, k, metric, d_scores[i], d_rows[i],
+ * d_keys ? d_keys[i] : NULL, d_status[i], streams[i % n_streams]) would, after announcing d_queries[i + n_streams] -- the
+ * batch the same stream searches next -- with rq_search_hint_next_device.  The pointer tables are HOST arrays of device
+ * pointers; d_queries holds n_batches + n_streams entries, the last n_streams of which are only announced (the first
+ * batches of the NEXT train; NULL = nothing to announce).  Results are complete per stream after rq_search_flush_device,
+ * as for single calls.  Replaces, n_batches times over, the collection.query of reference rag_uq/streaming_index.py:355-359. */
+int rq_search_train_device(rq_index* idx, int n_batches, const float* const* d_queries, int B, int k, int metric,
+                           float* const* d_scores, int64_t* const* d_rows, uint64_t* const* d_keys, int* const* d_status,
+                           void* const* streams, int n_streams);
 /* The library keeps one search workspace per caller stream (about 11 MB at 1M rows and 64 queries).  Call this before a
  * stream that has been used for searches is destroyed, or when it will not be used again: waits for the device, runs
  * any deferred tail, frees the stream's workspace.  (Beyond 8 streams the library drops idle workspaces by itself.) */
@@ -141,8 +152,13 @@ int rq_merge_keys_device(const uint64_t* d_keys_in, int n_per_query, int B, int 
  *   whose errors add up to the repair path of rq_search_fixup_device.  When more than 1 in 16 checked queries of a class of
  *   k (<= 32 / larger) needed repair, that class moves one step along one image -> two images -> fp16 scan, until "scan8" or
  *   "scan8_split" is set again),
+ * "wide256_8" (default 20: calls of more than 128 queries on the one-image class use 256-query passes over the image, a variant of
+ *   csrc/rq_scan_wide.hip; 0 = passes of 128 as in round 2), "bin_bound" (A/B hook, default 1: the tail tests every bin with its own rows'
+ *   worst quantisation error instead of the shard's), "stripe_rows" (multi-device index, before the first append: rows per stripe),
  * "tail_local" (A/B hook, default 1: a tail workgroup with more than k re-scored rows publishes only its own k best keys),
  * "poison_cand" (test hook: candidate lists are filled with 0xff..ff keys before every tail).
+ * "scan8" = 1 measures where the ladder STARTS when the image is built (64 stored rows searched as queries through every rung, the
+ *   fastest rung that certifies wins; "scan8_calibrated_rows", "scan8_calib_ms_<class><rung>", "scan8_calib_unc_<class><rung>" report it).
  * Read-only: "scan8_used" (searches that scanned the int8 image), "scan8_row_err" (worst row's relative int8 error, -1 = image
  * not built), "scan8_level" (ladder position: class k <= 32 + 10 * class of larger k; 0 one image, 1 two images, 2 fp16 scan),
  * "scan8_suspended" (bit 0 / 1: that class is back at the fp16 scan), "hints_used" (searches that found their queries prepared, see rq_search_hint_next_device), "max_row_norm", "max_sub_rel" / "max_sub_abs" (largest share of a stored row that sits in fp16-subnormal elements,
@@ -169,6 +185,9 @@ rq_index* rq_load(const char* path, int n_devices, const int* device_ids);
 /* Test hook: copy the scan's approximate per-bin maxima of query `query` of the LAST search enqueued on `stream`
  * (bin b = rows 64 b .. 64 b + 63) to the host.  Returns the number of bins copied. */
 int64_t rq_debug_pooled(rq_index* idx, void* stream, int query, float* out, int64_t max_bins);
+/* Test hook: the int8 image's worst relative row error of every bin (fp32, rounded up), i.e. what the tail may lift its candidate
+ * threshold by per bin (option "bin_bound").  Fails unless the image is built and up to date.  Returns the number of bins copied. */
+int64_t rq_debug_bin_err(rq_index* idx, float* out, int64_t max_bins);
 
 /* Measurement hook: GB/s of a plain streaming read (16-byte loads, nothing else) of the stored shard, averaged over
  * `iters` back-to-back passes -- what THIS GPU delivers right now, the yardstick for the scan kernel's rate.

@@ -685,9 +685,11 @@ def test_wide_batches_at_headline_size_match_oracle():
     s500, r500 = idx.search(q500, 100)
     dq = torch.from_numpy(q256).to(dev)
     sc = torch.empty((256, 10), device=dev); rw = torch.empty((256, 10), device=dev, dtype=torch.int64); st = torch.full((256,), 9, device=dev, dtype=torch.int32)
+    used = int(idx.get_option("scan8_used"))
     idx.search_device(dq, 256, 10, 0, sc, rw, None, st, 0)
     torch.cuda.synchronize()
     assert int(st.abs().sum()) == 0
+    assert int(idx.get_option("scan8_used")) == used + 1     # (round 3: ONE 256-query pass over the int8 image, csrc/rq_scan_wide.hip I8)
     t = idx.timing()
     assert t["widened"] == 0 and t["exact_scans"] == 0
     x16 = idx.get_rows_f16(0, n)
@@ -1545,6 +1547,29 @@ def test_int8_wide_passes_match_oracle():
         if B == 128:
             idx.add_f16(x16[50_011:]); n = 60_000                  # the image follows the append
     _check(idx, x16, 2.5 * orc.synthetic_queries(130, 768, seed=3), 10, nat.METRIC_IP)
+    # round 3: 256 queries per pass over the image (csrc/rq_scan_wide.hip I8: 8 waves x 2 groups, a stage = two 16-row tiles, a
+    # quad = two stages, the ring two quads): every built variant, ragged last passes (256 + 1, 256 + 128 + 3, 2 x 256 + 64), a shard
+    # whose workgroups own an ODD number of quads (ring parity), and 0 = off (passes of 128 as in round 2)
+    q600 = orc.synthetic_queries(600, 768, seed=17)
+    q600[5] = x16[7].astype(np.float32); q600[300] = 0
+    for variant in (20, 21, 22, 0):
+        idx.set_option("wide256_8", variant)
+        for B in ((129, 257, 387, 576) if variant == 20 else (257,)):
+            before = int(idx.get_option("scan8_used"))
+            _check(idx, x16, q600[:B], 10)
+            assert int(idx.get_option("scan8_used")) == before + 1, (variant, B)
+    idx.set_option("wide256_8", 20)
+    _check(idx, x16, 1.5 * q600[:300], 7, nat.METRIC_IP)
+    odd = nat.NativeIndex(768, 0)
+    odd.add_f16(x16[:256 * 3 * 64 + 64 * 5 + 9])               # 773 quads over 256 workgroups: 3 or 4 each
+    odd.set_option("scan8", 2)
+    _check(odd, x16[:256 * 3 * 64 + 64 * 5 + 9], q600[:260], 10)
+    odd.set_option("cu_count", 3)                                # 3 workgroups of ~258 quads: the record staging flushes many times
+    _check(odd, x16[:256 * 3 * 64 + 64 * 5 + 9], q600[:260], 10)
+    assert int(odd.get_option("scan8_used")) == 2
+    odd.close()
+    with pytest.raises(nat.RqError):
+        idx.set_option("wide256_8", 7)
     before = int(idx.get_option("scan8_used"))
     _check(idx, x16, orc.synthetic_queries(130, 768, seed=4), 100)  # k > 32: two-image class -> the fp16 wide passes
     idx.set_option("wide8", 0)
@@ -1615,3 +1640,122 @@ def _small_index(x16):
     idx = nat.NativeIndex(768, 0)
     idx.add_f16(x16)
     return idx
+
+
+def test_int8_bin_errors_bound_each_bin_and_lift_the_threshold():
+    """Round 3: rq_quant_rows_kernel keeps, per bin of 64 rows, the worst row's relative quantisation error (rq_debug_bin_err); the tail
+    tests a bin against T + (1 + e_q)(shard's worst row - the bin's).  (a) every per-bin value is the maximum of its rows' errors
+    recomputed in numpy (rounded up), their maximum is the shard's figure; (b) the scan's per-bin maxima stay within the PER-BIN bound
+    e_q + (1 + e_q)(bin + 2e-5) of the exact ones; (c) with the lift the tail re-scores fewer rows and returns the same exact answers."""
+    import torch
+    n = 131_072 + 40
+    x16 = orc.synthetic_corpus(n, 768, seed=91)
+    x16[1000:1064] = (x16[1000:1064].astype(np.float32) * np.linspace(0.2, 3.0, 768, dtype=np.float32)).astype(np.float16)   # a bin that quantises worse
+    idx = nat.NativeIndex(768, 0)
+    idx.add_f16(x16)
+    idx.set_option("scan8", 2)
+    q = orc.synthetic_queries(64, 768, seed=92)
+    _check(idx, x16, q, 10)
+    be = idx.debug_bin_err((n + 63) // 64)
+    assert be.shape[0] == (n + 63) // 64
+    xf = x16.astype(np.float64)
+    am = np.abs(xf).max(1)
+    sr = (am.astype(np.float32) / np.float32(127.0)).astype(np.float64)
+    inv = (np.float32(127.0) / am.astype(np.float32)).astype(np.float32)
+    q8 = np.clip(np.rint(x16.astype(np.float32) * inv[:, None]), -127, 127).astype(np.float64)
+    err = np.sqrt(((xf - sr[:, None] * q8) ** 2).sum(1)) / np.sqrt((xf * xf).sum(1))
+    pad = np.zeros(((n + 63) // 64) * 64); pad[:n] = err
+    want = pad.reshape(-1, 64).max(1)
+    assert np.all(be >= want * (1 - 1e-6)) and np.all(be <= want * (1 + 1e-5) + 1e-9), float(np.abs(be - want).max())
+    assert abs(float(be.max()) - idx.get_option("scan8_row_err")) <= 1e-6 * float(be.max())
+    assert be[1000 // 64] > 1.2 * np.median(be)
+    # (b) per-bin bound on the scan's bin maxima
+    exact = orc.exact_scores(q[:4], x16)
+    qn = q[:4].astype(np.float64); qa = np.abs(qn).max(1); sq = (qa.astype(np.float32) / np.float32(127.0)).astype(np.float64)
+    qq = np.clip(np.rint(q[:4] * (np.float32(127.0) / qa.astype(np.float32))[:, None]), -127, 127)
+    eq = np.sqrt(((qn - sq[:, None] * qq) ** 2).sum(1)) / np.sqrt((qn * qn).sum(1))
+    dq = torch.from_numpy(q).cuda()
+    sc = torch.empty((64, 10), device="cuda"); rw = torch.empty((64, 10), device="cuda", dtype=torch.int64); st = torch.zeros((64,), device="cuda", dtype=torch.int32)
+    idx.search_device(dq, 64, 10, 0, sc, rw, None, st, 0); torch.cuda.synchronize()
+    for j in range(4):
+        got = idx.debug_pooled(j, (n + 63) // 64)
+        ex = np.full(((n + 63) // 64) * 64, -np.inf); ex[:n] = exact[j]
+        exm = ex.reshape(-1, 64).max(1)
+        bound = eq[j] + (1 + eq[j]) * (be.astype(np.float64) * 1.000001 + 2e-5) + 3e-6      # (+ the record's 26-bit round-up)
+        assert np.all(np.abs(got.astype(np.float64) - exm) <= bound), float((np.abs(got - exm) - bound).max())
+    # (c) fewer candidate rows, identical answers
+    cands = {}
+    for bb in (0, 1):
+        idx.set_option("bin_bound", bb)
+        idx.set_option("tail_stop", 5)
+        idx.search_device(dq, 64, 10, 0, sc, rw, None, st, 0); torch.cuda.synchronize()
+        cands[bb] = st.cpu().numpy().copy()
+        idx.set_option("tail_stop", 0)
+        idx.search_device(dq, 64, 10, 0, sc, rw, None, st, 0); torch.cuda.synchronize()      # (resets the counters a truncated tail leaves)
+        _check(idx, x16, q, 10)
+        _check(idx, x16, 3.0 * q[:9], 50, nat.METRIC_IP)
+    assert (cands[1] <= cands[0]).all() and cands[1].sum() < 0.9 * cands[0].sum(), (int(cands[0].sum()), int(cands[1].sum()))
+    idx.close()
+
+
+def _structured_corpus(kind, n, seed):
+    import torch
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    cent = torch.randn((64, 768), device=dev, generator=g)
+    docs = torch.randn((n // 16 + 1, 768), device=dev, generator=g)
+    noise = torch.randn((n, 768), device=dev, generator=g)
+    if kind == "centroids":
+        x = cent[torch.randint(0, 64, (n,), device=dev, generator=g)] + 0.3 * noise
+        q = cent[torch.randint(0, 64, (64,), device=dev, generator=g)] + 0.3 * torch.randn((64, 768), device=dev, generator=g)
+    elif kind == "documents":
+        x = docs[(torch.arange(n, device=dev) // 16)] + 0.5 * noise
+        q = docs[torch.randint(0, n // 16, (64,), device=dev, generator=g)] + 0.3 * torch.randn((64, 768), device=dev, generator=g)
+    else:
+        x = noise
+        q = torch.randn((64, 768), device=dev, generator=g)
+    return torch.nn.functional.normalize(x, dim=1).half().contiguous(), q.contiguous()
+
+
+@pytest.mark.parametrize("kind", ["gaussian", "centroids", "documents"])
+def test_int8_ladder_start_is_measured_at_image_build(kind):
+    """Round 3: with "scan8" = 1 the library decides where the int8 ladder starts when it builds the image -- 64
+    stored rows searched as queries through every rung, the fastest rung that certifies wins -- instead of after slow batches.  On a
+    clustered corpus (64 tight centroids, on-topic queries: round 2 paid hundreds of uncertified queries and widened passes before the
+    class reached the fp16 scan) the FIRST caller batch already runs at the steady-state operand: nothing uncertified, nothing widened,
+    from the first call on.  On Gaussian rows the image wins and is used.  Results equal the oracle either way."""
+    import torch
+    n = 300_000
+    x, q = _structured_corpus(kind, n, 11)
+    idx = nat.NativeIndex(768, 0)
+    idx.add_f16_device(x, n)
+    del x
+    idx.set_option("scan8", 1)
+    assert idx.get_option("scan8_calibrated_rows") == 0
+    sc = torch.empty((64, 10), device="cuda"); rw = torch.empty((64, 10), device="cuda", dtype=torch.int64); st = torch.zeros((64,), device="cuda", dtype=torch.int32)
+    idx.search_device(q, 64, 10, 0, sc, rw, None, st, 0); torch.cuda.synchronize()           # builds the image, measures, then searches
+    assert idx.get_option("scan8_calibrated_rows") == n
+    level = int(idx.get_option("scan8_level")) % 10
+    ms = [idx.get_option(f"scan8_calib_ms_0{l}") for l in range(3)]
+    unc = [int(idx.get_option(f"scan8_calib_unc_0{l}")) for l in range(3)]
+    assert all(m > 0 for m in ms) and unc[2] == 0
+    assert unc[level] * 16 <= 64 and ms[level] <= min(m for m, u in zip(ms, unc) if u * 16 <= 64) * 1.0001
+    first_unc = int(st.sum())
+    t0 = idx.timing()
+    for rep in range(6):
+        idx.search_device(q, 64, 10, 0, sc, rw, None, st, 0); torch.cuda.synchronize()
+        assert int(st.sum()) <= 4
+        idx.search_fixup_device(q, 64, 10, 0, sc, rw, None, st, 0)
+    t1 = idx.timing()
+    assert first_unc <= 4 and t1["exact_scans"] == t0["exact_scans"], (kind, first_unc, t0, t1)
+    assert int(idx.get_option("scan8_level")) % 10 == level                     # the measured start holds: no escalation after slow batches
+    if kind == "gaussian":
+        assert level == 0 and int(idx.get_option("scan8_used")) >= 7            # the image pays on Gaussian rows: one image per query
+    if kind == "centroids":
+        assert level == 2 and t1["widened"] == t0["widened"] and int(idx.get_option("scan8_used")) == 0   # clusters: the fp16 rows from the first call on
+    x16 = idx.get_rows_f16(0, n)
+    gs, gr = orc.dense_topk(q.cpu().numpy()[:16], x16, 10)
+    assert np.array_equal(rw.cpu().numpy()[:16], gr) and float(np.abs(sc.cpu().numpy()[:16] - gs).max()) <= SCORE_TOL
+    idx.set_option("scan8", 2)                                                    # "always": no measurement, round 2's start levels
+    assert idx.get_option("scan8_level") == 10.0 and idx.get_option("scan8_calibrated_rows") == 0
+    idx.close()

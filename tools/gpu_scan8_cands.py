@@ -15,13 +15,13 @@ gq = torch.Generator(device=dev); gq.manual_seed(4321)
 q = torch.randn((64, 768), device=dev, generator=gq)
 for k in (10, 100):
     sc = torch.empty((64, k), device=dev); rw = torch.empty((64, k), device=dev, dtype=torch.int64); st = torch.zeros((64,), device=dev, dtype=torch.int32)
-    for mode, mult in ((0, 0), (1, 1.25), (1, 1.1)):
-        idx.set_option("scan8", mode)
+    for mode, mult, bb in ((0, 0, 1), (2, 1.25, 0), (2, 1.25, 1), (2, 1.1, 1)):
+        idx.set_option("scan8", mode); idx.set_option("bin_bound", bb)
         if mode: idx.set_option("thr_mult8", mult)
         idx.set_option("tail_stop", 5)
         idx.search_device(q, 64, k, 0, sc, rw, None, st, 0); torch.cuda.synchronize()
         c = st.cpu().numpy()
-        print(f"k={k} scan8={mode} mult={mult}: candidate rows per query min {c.min()} median {int(np.median(c))} max {c.max()}", flush=True)
+        print(f"k={k} scan8={mode} mult={mult} bin_bound={bb}: candidate rows per query min {c.min()} median {int(np.median(c))} max {c.max()}", flush=True)
         idx.set_option("tail_stop", 0)
         idx.search_device(q, 64, k, 0, sc, rw, None, st, 0); torch.cuda.synchronize()   # (resets the counters a truncated tail leaves)
 idx.close()
