@@ -309,7 +309,7 @@ extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     else if (s == "epi" || s == "fused_epi") idx->epi = (int)v != 0;   // selection form of the 64-query scan (default variant and fused launch): 1 = positions inside the scores, 0 = compare / select
     else if (s == "profile_legacy") idx->profile_legacy = (int)v != 0;   // time scans with hipEventRecord around the launch (round 1) instead of dispatch-attached events
     else if (s == "scan8") { if (v < 0 || v > 2) return set_err(RQ_EINVAL, "scan8 must be 0, 1 or 2"); idx->scan8 = (int)v; scan8_reset_levels(idx); }   // see run_pipeline
-    else if (s == "wide256_8") { if (v != 0 && (v < 20 || v > 22)) return set_err(RQ_EINVAL, "wide256_8: 0 (off) or a 256-query int8 variant of csrc/rq_scan_wide.hip (20..22)"); idx->wide256_8 = (int)v; }
+    else if (s == "wide256_8") { if (v != 0 && v != 24 && (v < 20 || v > 22)) return set_err(RQ_EINVAL, "wide256_8: 0 (off) or a 256-query int8 variant of csrc/rq_scan_wide.hip (20..22, 24)"); idx->wide256_8 = (int)v; }
     else if (s == "wide8") idx->wide8 = (int)v != 0;   // calls of more than 64 queries may use 128-query passes over the int8 image
     else if (s == "scan8_split") { if (v < -1 || v > 1) return set_err(RQ_EINVAL, "scan8_split must be -1, 0 or 1"); idx->scan8_split = (int)v; scan8_reset_levels(idx); }   // see run_pipeline
     else if (s == "thr_mult8") { if (!(v >= 1.05 && v <= 2.25)) return set_err(RQ_EINVAL, "thr_mult8 %g outside 1.05..2.25", v); idx->thr_mult8 = v; }
@@ -534,7 +534,7 @@ static int ensure_x8(rq_index* idx, hipStream_t s) {
         hipError_t e = hipMalloc((void**)&idx->x8, (size_t)idx->cap * RQ_DPAD);
         if (e == hipSuccess) e = hipMalloc((void**)&idx->scale8_cos, (size_t)idx->cap * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void**)&idx->scale8_ip, (size_t)idx->cap * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc((void**)&idx->binerr8, (size_t)(idx->cap / 64) * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&idx->binerr8, (size_t)(idx->cap / 64 + 64) * sizeof(float));   // (+64: the tail reads whole record strides)
         if (e == hipSuccess && !idx->d_stat8) e = hipMalloc((void**)&idx->d_stat8, sizeof(unsigned long long));
         if (e != hipSuccess) {   // no room for the image (+50 % of the shard): not an error, the fp16 rows remain the scan operand
             drop_x8(idx);
@@ -546,7 +546,7 @@ static int ensure_x8(rq_index* idx, hipStream_t s) {
         HIPCHK(hipMemsetAsync(idx->scale8_cos, 0xff, (size_t)idx->cap * sizeof(float), s));   // pad rows: NaN (see grow)
         HIPCHK(hipMemsetAsync(idx->scale8_ip, 0xff, (size_t)idx->cap * sizeof(float), s));
         HIPCHK(hipMemsetAsync(idx->d_stat8, 0, sizeof(unsigned long long), s));
-        HIPCHK(hipMemsetAsync(idx->binerr8, 0, (size_t)(idx->cap / 64) * sizeof(float), s));
+        HIPCHK(hipMemsetAsync(idx->binerr8, 0, (size_t)(idx->cap / 64 + 64) * sizeof(float), s));
         idx->x8_valid = 0; idx->max_e8 = 0.0;
     }
     HIPCHK(rq_quant_rows_launch(idx->x, idx->rownorm64, idx->x8_valid, idx->n, idx->x8, idx->scale8_cos, idx->scale8_ip, idx->d_stat8, idx->binerr8, s));

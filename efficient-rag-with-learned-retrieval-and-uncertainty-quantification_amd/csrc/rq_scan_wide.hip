@@ -50,7 +50,7 @@ template <bool NT, int D, int QW, int QG, int EPI, int DBG = 0, int PRIO = 0, in
 __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, const int G) {
     static_assert(D >= 2 && D <= 12 && 24 % D == 0, "prefetch distance");
     static_assert(QW == 4 || QW == 8, "waves per workgroup");
-    static_assert(QG == 1 || QG == 2, "query groups per wave");
+    static_assert(QG == 1 || QG == 2 || QG == 4, "query groups per wave");
     static_assert(I8 == 0 || (EPI == 1 && DBG == 0 && PRIO != 2), "int8 form: med3 selection only");
     constexpr int ROWB = I8 ? RQ_DPAD : RQ_DPAD * 2;   // bytes per corpus row
     constexpr int KS = I8 ? 12 : 24;               // k-steps = LDS fragments per tile
@@ -171,13 +171,16 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
         }
         return *(const rq_half8*)(rq_smem_w + t * STAGE_BYTES + (rbase0 ^ (unsigned)((s & 3) << 6)) + ((s & ~3) << 6));
     };
+    int nq_valid_r = 0;          // (set below, once the kernel arguments are pinned in registers)
+    int64_t bins_stride_r = 0;
+    uint2* bins_r = nullptr;
     auto flush = [&](int quad0, int count) {
         // each wave writes the rows of its own 16 QG queries: 64 / SQ queries x SQ records (8 SQ-byte runs) per instruction
         constexpr int QPI = 64 / SQ;
 #pragma unroll 1
         for (int i = 0; i < 16 * QG / QPI; ++i) {
             const int ql = 16 * QG * wave + QPI * i + lane / SQ, j = lane & (SQ - 1);
-            if (j < count && ql < a.nq_valid) a.bins[(int64_t)ql * a.bins_stride + quad0 + j] = stg[ql * SQ + j];
+            if (j < count && ql < nq_valid_r) bins_r[(int64_t)ql * bins_stride_r + quad0 + j] = stg[ql * SQ + j];
         }
     };
 
@@ -185,6 +188,18 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
     if (PRIO == 1 && QW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
     rq_half8 av[D];   // fragment ring: fragment f of the quad lives in av[f % D]
     if (I8) set_bases(0);
+    // The counted lgkmcnt waits below are sound only while LDS operations are the ONLY users of that counter: LDS returns in
+    // order, scalar (kernel-argument) loads do not, and one s_load still in flight when the first fragment reads are issued can
+    // satisfy "at most D outstanding" in place of the oldest ds_read (round 3: the compiler had sunk the load of a.nq_valid to just
+    // before the loop of the int8 form; queries of some waves then multiplied a stale register in their first tile).  Every
+    // argument the loop and the epilogue use is therefore pinned in registers here, and the queue is drained once.
+    int nq_valid = a.nq_valid, wgmax_stride = a.wgmax_stride;
+    int64_t bins_stride = a.bins_stride;
+    uint2* bins_p = a.bins;
+    float* wgmax_p = a.wgmax;
+    asm volatile("" : "+s"(nq_valid), "+s"(wgmax_stride), "+s"(bins_stride), "+s"(bins_p), "+s"(wgmax_p));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    nq_valid_r = nq_valid; bins_stride_r = bins_stride; bins_r = bins_p;
     acquire(0);
 #pragma unroll
     for (int f = 0; f < D; ++f) av[f] = frag(f / KS, f % KS, false);
@@ -352,7 +367,7 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
         const int ql = 16 * (QG * wave + g) + r16;
-        if (kg == 0 && ql < a.nq_valid) a.wgmax[(int64_t)ql * a.wgmax_stride + b] = wmax[g];
+        if (kg == 0 && ql < nq_valid) wgmax_p[(int64_t)ql * wgmax_stride + b] = wmax[g];
     }
 }
 
@@ -407,6 +422,9 @@ hipError_t rq_scan_wide_launch(const RqScanArgs& a, int variant, int queries, bo
     //                        21  as 20, reads 6 ahead;  22  as 20, compiler-scheduled reads;  23  128 queries (8 waves x 1 group), reads 12 ahead
     RQW_CASE(20, 12, 2, 8, 2, 1, 0, 3, 1) RQW_CASE(21, 6, 2, 8, 2, 1, 0, 3, 1) RQW_CASE(22, 12, 2, 8, 2, 1, 0, 0, 1)
     RQW_CASE(23, 12, 2, 8, 1, 1, 0, 3, 1)
+    // 24  256 queries as 4 waves x 4 groups (one wave per SIMD, 192 VGPRs of query fragments): every LDS fragment feeds four MFMAs, half the
+    //     LDS read traffic of 20 (A/B)
+    RQW_CASE(24, 12, 1, 4, 4, 1, 0, 3, 1)
     RQW_CASE(90, 4, 2, 8, 1, 0, 1) RQW_CASE(91, 4, 2, 8, 1, 0, 2) RQW_CASE(92, 4, 2, 8, 1, 0, 3)
     RQW_CASE(93, 12, 2, 8, 1, 1, 1) RQW_CASE(94, 12, 2, 8, 1, 1, 2) RQW_CASE(95, 12, 2, 8, 1, 1, 3)
 #undef RQW_CASE

@@ -886,27 +886,33 @@ class HybridRetriever:
             res = [self.dense_index.search(q, top_k) for q in queries]
         return [[(d, s) for d, s, _ in r] for r in res]
 
-    def _fuse(self, bm25_list: List[Tuple[str, float]], dense_list: List[Tuple[str, float]], top_k: int) -> List[RetrievalResult]:
-        """Reference :485-523: union of both pools, ids unknown to `self.documents` dropped, missing
-        score 0.0, hybrid = (bm25/max_bm25 + dense/max_dense)/2 with `max(...) or 1`, stable sort desc.
-        The reference walks a Python set (arbitrary order); here the union is walked in first-seen
-        order (BM25 pool, then dense pool), one admissible instance of that order."""
+    def _fuse_columns(self, bm25_list: List[Tuple[str, float]], dense_list: List[Tuple[str, float]], top_k: int):
+        """Reference :485-523 on parallel lists: union of both pools, ids unknown to `self.documents` dropped, missing score 0.0,
+        hybrid = (bm25/max_bm25 + dense/max_dense)/2 with `max(...) or 1` over ALL candidates, stable sort desc, first top_k.
+        The reference walks a Python set (arbitrary order); here the union is walked in first-seen order (BM25 pool, then dense
+        pool), one admissible instance of that order.  Returns (ids, bm25 scores, dense scores, hybrid scores) of the top_k --
+        the RetrievalResult objects (2 us each, 200 candidates per question) are only built for what is returned."""
         bm25_results = dict(bm25_list)
         dense_results = dict(dense_list)
-        results: List[RetrievalResult] = []
-        for doc_id in dict.fromkeys(list(bm25_results) + list(dense_results)):
-            doc = self.documents.get(doc_id)
-            if doc is None:
-                continue
-            results.append(RetrievalResult(doc_id=doc_id, text=doc.text, bm25_score=bm25_results.get(doc_id, 0.0),
-                                           dense_score=dense_results.get(doc_id, 0.0), title=doc.title, metadata=doc.metadata))
-        if results:
-            max_bm25 = max(r.bm25_score for r in results) or 1
-            max_dense = max(r.dense_score for r in results) or 1
-            for r in results:
-                r.hybrid_score = (r.bm25_score / max_bm25 + r.dense_score / max_dense) / 2
-            results.sort(key=lambda x: x.hybrid_score or 0, reverse=True)
-        return results[:top_k]
+        documents = self.documents
+        ids = [d for d in dict.fromkeys(list(bm25_results) + list(dense_results)) if d in documents]
+        if not ids:
+            return [], [], [], []
+        b = [bm25_results.get(d, 0.0) for d in ids]
+        de = [dense_results.get(d, 0.0) for d in ids]
+        max_bm25 = max(b) or 1
+        max_dense = max(de) or 1
+        h = [(x / max_bm25 + y / max_dense) / 2 for x, y in zip(b, de)]
+        order = sorted(range(len(ids)), key=lambda i: h[i] or 0, reverse=True)[:top_k]      # stable, like list.sort(reverse=True)
+        return [ids[i] for i in order], [b[i] for i in order], [de[i] for i in order], [h[i] for i in order]
+
+    def _fuse(self, bm25_list: List[Tuple[str, float]], dense_list: List[Tuple[str, float]], top_k: int) -> List[RetrievalResult]:
+        ids, b, de, h = self._fuse_columns(bm25_list, dense_list, top_k)
+        out = []
+        for doc_id, bs, ds, hs in zip(ids, b, de, h):
+            doc = self.documents[doc_id]
+            out.append(RetrievalResult(doc_id=doc_id, text=doc.text, bm25_score=bs, dense_score=ds, hybrid_score=hs, title=doc.title, metadata=doc.metadata))
+        return out
 
     def hybrid_search(self, query: str, top_k: int = 10, retrieval_pool_size: int = 50) -> List[RetrievalResult]:
         return self._fuse(self.bm25_search(query, retrieval_pool_size), self.dense_search(query, retrieval_pool_size), top_k)
@@ -914,6 +920,10 @@ class HybridRetriever:
     def hybrid_search_batch(self, queries: Sequence[str], top_k: int = 10, retrieval_pool_size: int = 50) -> List[List[RetrievalResult]]:
         """All dense pools from one GPU batch, all BM25 pools from one pass over the posting lists on the host cores (librq_bm25.so);
         fusion per query."""
+        dense, sparse = self._pools_batch(queries, retrieval_pool_size)
+        return [self._fuse(sparse[i], dense[i], top_k) for i in range(len(queries))]
+
+    def _pools_batch(self, queries: Sequence[str], retrieval_pool_size: int):
         dense = self.dense_search_batch(queries, retrieval_pool_size)
         if self.bm25_index is None:
             sparse = [[] for _ in queries]
@@ -921,7 +931,7 @@ class HybridRetriever:
             sparse = self.bm25_index.search_batch(list(queries), retrieval_pool_size)
         else:
             sparse = [self.bm25_search(q, retrieval_pool_size) for q in queries]
-        return [self._fuse(sparse[i], dense[i], top_k) for i in range(len(queries))]
+        return dense, sparse
 
     @staticmethod
     def _router_arrays(results: List[RetrievalResult], num_passages: int):
@@ -944,8 +954,19 @@ class HybridRetriever:
         return self._router_arrays(self.hybrid_search(query, top_k=num_passages, retrieval_pool_size=retrieval_pool_size), num_passages)
 
     def get_scores_for_router_batch(self, queries: Sequence[str], num_passages: int = 20, *, retrieval_pool_size: int = 50):
-        return [self._router_arrays(r, num_passages)
-                for r in self.hybrid_search_batch(queries, top_k=num_passages, retrieval_pool_size=retrieval_pool_size)]
+        """`[get_scores_for_router(q, ...) for q in queries]` with the pools of the whole batch computed at once and the four padded
+        lists assembled straight from the fused columns (no RetrievalResult objects in between)."""
+        dense, sparse = self._pools_batch(queries, retrieval_pool_size)
+        documents = self.documents
+        out = []
+        for i in range(len(queries)):
+            ids, b, de, _ = self._fuse_columns(sparse[i], dense[i], num_passages)
+            texts = [documents[d].text for d in ids]
+            pad = num_passages - len(ids)
+            if pad > 0:
+                b = b + [0.0] * pad; de = de + [0.0] * pad; ids = ids + [""] * pad; texts = texts + [""] * pad
+            out.append((b, de, ids, texts))
+        return out
 
     def close(self) -> None:
         """Write the BM25 snapshot if documents were added since the last one (extension; the reference has no close)."""

@@ -114,6 +114,29 @@ def test_record_codec_properties_on_the_host(tmp_path):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+def test_host_code_under_address_and_ub_sanitizers(tmp_path):
+    """CPU-only sanitizer builds (the GPU boxes of this pool cannot run sanitizers): -fsanitize=address,undefined over (a) the
+    record / key codecs of csrc/rq_device.h, (b) the multi-device parent of csrc/rq_multi.hip -- stripe arithmetic, row read-back,
+    k-way merge incl. its threads, the poisoned / failed-search paths -- behind STUBBED shards (tests/native/multi_check.cpp), and
+    (c) librq_bm25's scorer (csrc/rq_bm25.cpp compiled into tests/native/bm25_check.cpp).  Any report aborts the program."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    gxx = shutil.which("g++")
+    if not os.path.exists(hipcc) or gxx is None:
+        pytest.skip("hipcc / g++ not available")
+    san = ["-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"]
+    native = os.path.join(os.path.dirname(__file__), "native")
+    jobs = [([hipcc, "--offload-host-only", *san, "-I", CSRC, os.path.join(native, "codec_check.cpp")], "codec"),
+            ([hipcc, "--offload-host-only", *san, "-I", CSRC, os.path.join(native, "multi_check.cpp")], "multi"),
+            ([gxx, *san, "-I", os.path.join(ROOT, "include"), os.path.join(native, "bm25_check.cpp"), os.path.join(CSRC, "rq_bm25.cpp")], "bm25")]
+    for cmd, name in jobs:
+        exe = str(tmp_path / f"{name}_san")
+        subprocess.run(cmd + ["-o", exe], check=True, timeout=600, capture_output=True)
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=600, env={**os.environ, "ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0"})
+        assert out.returncode == 0 and "0 failures" in out.stdout, f"{name}: {out.stdout[-1500:]}{out.stderr[-3000:]}"
+
+
 def _build_c_client(tmp_path):
     import shutil
     import subprocess

@@ -40,4 +40,9 @@ def test_config4_hybrid_top100_through_router_recall_at_10():
     r = cw.run_config4()
     assert r["router_inputs_identical"] and r["id_lists_identical"], r
     assert r["recall_at_10_router_gpu_dense"] == r["recall_at_10_router_oracle_dense"]
-    assert r["recall_at_10_dense_only"] > 0.5 and r["recall_at_10_fusion_only"] > 0.9, r    # the stand-in task is solvable
+    # The stand-in task is solvable -- these are sanity bounds on the SYNTHETIC data, not parity assertions (parity is the three
+    # lines above).  Dense-only Recall@10 is 0.876 on this seed, deterministically: a 12-word question shares 8 words with its
+    # 40-word passage and carries 4 distractors, and RandomProjectionEmbedder is a bag of random word directions, so 12 % of the
+    # answers rank below 10 neighbours that happen to share frequent words.  (Round 2 first wrote "> 0.9" from a guess, saw 0.876 in
+    # gpurun_out/r02_t5.log and dropped the bound to 0.5; 0.85 is the measured value with a margin for a different numpy RNG stream.)
+    assert r["recall_at_10_dense_only"] > 0.85 and r["recall_at_10_fusion_only"] > 0.9, r

@@ -1079,6 +1079,12 @@ def test_many_caller_streams_do_not_pile_up_workspaces():
         run(s)
     torch.cuda.synchronize()
     free40, _ = torch.cuda.mem_get_info(dev)
+    # What this bounds: workspaces must not PILE UP -- 32 more streams would keep 32 x ~13 MB = 400+ MB if every stream kept one.
+    # The bound is "less than a handful of allocator granules", not "zero": a workspace is ~20 separate hipMallocs that the
+    # allocator rounds up to 2 MiB granules, and which 8 of the 40 streams still hold one at the end depends on where the drop-all
+    # rule (9th, 17th, 25th, 33rd stream) fell.  Measured: exactly 16 MiB (8 granules) in round 2's run (gpurun_out/r02_t7.log) --
+    # which is why the original "< 16 MiB" failed by one byte's worth; 48 MiB keeps a 3x margin over that and stays 8x below
+    # what a single leaked generation of 32 workspaces would show.
     assert free8 - free40 < 48 << 20, f"{(free8 - free40) >> 20} MiB more device memory after 32 further streams"
     idx.set_option("pipeline", 2)
     idx.search_device(dq, 64, 10, 0, sc, rw, None, st, streams[0].cuda_stream)     # a deferred tail is pending on this stream
@@ -1552,7 +1558,7 @@ def test_int8_wide_passes_match_oracle():
     # whose workgroups own an ODD number of quads (ring parity), and 0 = off (passes of 128 as in round 2)
     q600 = orc.synthetic_queries(600, 768, seed=17)
     q600[5] = x16[7].astype(np.float32); q600[300] = 0
-    for variant in (20, 21, 22, 0):
+    for variant in (20, 21, 22, 24, 0):
         idx.set_option("wide256_8", variant)
         for B in ((129, 257, 387, 576) if variant == 20 else (257,)):
             before = int(idx.get_option("scan8_used"))
@@ -1584,30 +1590,36 @@ def test_int8_ladder_counts_clean_calls_too():
     its failing calls to the int8 ladder (rq_search_end's clean branch counted nothing), so repaired / checked was always >= 1 and 256
     repaired queries IN TOTAL moved the class to the fp16 scan for good.  Now every checked query counts: 7 000 clean one-query calls
     with 280 queries that need repair among them (4 %, below the 1-in-16 rule) leave the level alone, results stay exact."""
-    x16 = orc.synthetic_corpus(40_000, 768, seed=61)
-    x16[5_000:5_900] = x16[4_999]                        # 901 identical rows: a query on them overflows its candidate lists at k = 10
+    xg = orc.synthetic_corpus(30_000, 768, seed=61)
+    xc = orc.synthetic_corpus(30_000, 768, seed=62, clustered=True)     # 64 tight centroids: ~470 rows within the int8 bound of an on-topic query
+    x16 = np.concatenate([xg, xc], 0)
     idx = nat.NativeIndex(768, 0)
     idx.add_f16(x16)
     idx.set_option("scan8", 2)
-    clean = orc.synthetic_queries(100, 768, seed=62)
-    dirty = x16[4_999].astype(np.float32)[None, :]
-    s, r = idx.search(dirty, 10)
-    assert r[0].tolist() == list(range(4_999, 5_009))    # ties by row id, exact
-    assert idx.get_option("scan8_level") == 10.0
+    clean = xg[::300][:100].astype(np.float32) + 0.2 * orc.synthetic_queries(100, 768, seed=63)    # near Gaussian rows: certified at once
+    dirty = xc[::997][:4].astype(np.float32) + 0.05 * orc.synthetic_queries(4, 768, seed=64)      # inside a cluster: candidate lists overflow
     t0 = idx.timing()
+    for i in range(4):
+        _check(idx, x16, dirty[i:i + 1], 10)
+    t1 = idx.timing()
+    assert t1["widened"] + t1["exact_scans"] >= t0["widened"] + t0["exact_scans"] + 4, "the on-topic queries are expected to need the repair ladder"
+    idx.set_option("scan8", 2)                            # start over: levels and windows
+    assert idx.get_option("scan8_level") == 10.0
     for rep in range(70):
         for i in range(100):
             idx.search(clean[i:i + 1], 10)
-        for _ in range(4):
-            idx.search(dirty, 10)
+        for i in range(4):
+            idx.search(dirty[i:i + 1], 10)
     assert idx.get_option("scan8_level") == 10.0, "4 % repaired queries must not move the k <= 32 class off the one-image scan"
-    t1 = idx.timing()
-    assert t1["widened"] + t1["exact_scans"] > t0["widened"] + t0["exact_scans"]      # (the dirty queries really were repaired)
+    t2 = idx.timing()
+    assert t2["widened"] + t2["exact_scans"] >= t1["widened"] + t1["exact_scans"] + 280 and t2["widened"] + t2["exact_scans"] < t1["widened"] + t1["exact_scans"] + 400
     _check(idx, x16, clean[:64], 10)
     # ... while a stream of nothing but failing one-query calls still escalates
-    for _ in range(600):
-        idx.search(dirty, 10)
+    for rep in range(150):
+        for i in range(4):
+            idx.search(dirty[i:i + 1], 10)
     assert int(idx.get_option("scan8_level")) % 10 >= 1
+    _check(idx, x16, dirty, 10)
     idx.close()
 
 
@@ -1685,6 +1697,7 @@ def test_int8_bin_errors_bound_each_bin_and_lift_the_threshold():
         assert np.all(np.abs(got.astype(np.float64) - exm) <= bound), float((np.abs(got - exm) - bound).max())
     # (c) fewer candidate rows, identical answers
     cands = {}
+    idx.set_option("tail_local", 0)                       # (every re-scored row is published: the counter below counts rows, not k per workgroup)
     for bb in (0, 1):
         idx.set_option("bin_bound", bb)
         idx.set_option("tail_stop", 5)

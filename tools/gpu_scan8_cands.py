@@ -16,7 +16,7 @@ q = torch.randn((64, 768), device=dev, generator=gq)
 for k in (10, 100):
     sc = torch.empty((64, k), device=dev); rw = torch.empty((64, k), device=dev, dtype=torch.int64); st = torch.zeros((64,), device=dev, dtype=torch.int32)
     for mode, mult, bb in ((0, 0, 1), (2, 1.25, 0), (2, 1.25, 1), (2, 1.1, 1)):
-        idx.set_option("scan8", mode); idx.set_option("bin_bound", bb)
+        idx.set_option("scan8", mode); idx.set_option("bin_bound", bb); idx.set_option("tail_local", 0)
         if mode: idx.set_option("thr_mult8", mult)
         idx.set_option("tail_stop", 5)
         idx.search_device(q, 64, k, 0, sc, rw, None, st, 0); torch.cuda.synchronize()
