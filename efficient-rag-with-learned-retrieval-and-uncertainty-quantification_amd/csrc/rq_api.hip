@@ -309,7 +309,7 @@ extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     else if (s == "epi" || s == "fused_epi") idx->epi = (int)v != 0;   // selection form of the 64-query scan (default variant and fused launch): 1 = positions inside the scores, 0 = compare / select
     else if (s == "profile_legacy") idx->profile_legacy = (int)v != 0;   // time scans with hipEventRecord around the launch (round 1) instead of dispatch-attached events
     else if (s == "scan8") { if (v < 0 || v > 2) return set_err(RQ_EINVAL, "scan8 must be 0, 1 or 2"); idx->scan8 = (int)v; scan8_reset_levels(idx); }   // see run_pipeline
-    else if (s == "wide256_8") { if (v != 0 && v != 24 && (v < 20 || v > 22)) return set_err(RQ_EINVAL, "wide256_8: 0 (off) or a 256-query int8 variant of csrc/rq_scan_wide.hip (20..22, 24)"); idx->wide256_8 = (int)v; }
+    else if (s == "wide256_8") { if (v != 0 && v != 22 && v != 25) return set_err(RQ_EINVAL, "wide256_8: 0 (off) or a 256-query int8 variant of csrc/rq_scan_wide.hip (22, 25)"); idx->wide256_8 = (int)v; }
     else if (s == "wide8") idx->wide8 = (int)v != 0;   // calls of more than 64 queries may use 128-query passes over the int8 image
     else if (s == "scan8_split") { if (v < -1 || v > 1) return set_err(RQ_EINVAL, "scan8_split must be -1, 0 or 1"); idx->scan8_split = (int)v; scan8_reset_levels(idx); }   // see run_pipeline
     else if (s == "thr_mult8") { if (!(v >= 1.05 && v <= 2.25)) return set_err(RQ_EINVAL, "thr_mult8 %g outside 1.05..2.25", v); idx->thr_mult8 = v; }
@@ -450,8 +450,8 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
 // was twice as slow as the fp16 one).  64 STORED rows, evenly spread, are searched as queries -- on-topic queries are the
 // hard case: their neighbourhoods are where the quantisation bound collects candidates -- through every rung (one image,
 // two images, fp16 rows) for each class of k (k = 10 for k <= 32, k = 100 beyond), timed with HIP events (prep + scan + tail,
-// plain sequential form, best of two).  A rung is eligible when at most 1 in 16 sample queries came back uncertified (the
-// ladder's own rule); the fastest eligible rung wins, the fp16 rows being always eligible.  Costs ~20 scans of the shard,
+// plain sequential form, best of three).  A rung is eligible when at most 1 in 16 sample queries came back uncertified (the
+// ladder's own rule); the LOWEST eligible rung wins unless a higher one is 8 % faster, the fp16 rows being always eligible.  Costs ~20 scans of the shard,
 // once per image build (and again when the shard has doubled).  "scan8" = 2 (always) skips this and starts as round 2 did.
 static int scan8_calibrate(rq_index* idx, hipStream_t s) {
     if (idx->scan8 != 1 || idx->calibrating || !idx->x8 || idx->n < 64 * 64) return RQ_OK;
@@ -483,15 +483,13 @@ static int scan8_calibrate(rq_index* idx, hipStream_t s) {
         for (int c = 0; c < 2; ++c) {
             const int k = c == 0 ? 10 : KMAX;
             if ((int64_t)k * 2 * 64 > idx->n) { idx->scan8_level[c] = 2; continue; }
-            float best_ms = 0.f;
-            int best = 2;
             float ms_of[3] = {0.f, 0.f, 0.f};
             int unc_of[3] = {0, 0, 0};
             for (int level = 2; level >= 0; --level) {          // fp16 first: always eligible
                 idx->scan8_level[c] = level;
                 float ms = 1e30f;
                 int unc = 0;
-                for (int rep = 0; rep < 3; ++rep) {             // (the first run warms the workspace of this shape)
+                for (int rep = 0; rep < 4; ++rep) {             // (the first run warms the workspace of this shape)
                     HIPCHK(hipEventRecord(e0, s));
                     if (int r = run_pipeline(idx, d_q, S, k, RQ_METRIC_COSINE, nb_default(idx, k), d_sc, d_rw, nullptr, d_st, s, false, false, level < 2)) return r;
                     HIPCHK(hipEventRecord(e1, s));
@@ -504,9 +502,14 @@ static int scan8_calibrate(rq_index* idx, hipStream_t s) {
                 HIPCHK(hipMemcpy(st, d_st, sizeof st, hipMemcpyDeviceToHost));
                 for (int i = 0; i < S; ++i) unc += st[i] != 0;
                 ms_of[level] = ms; unc_of[level] = unc;
-                const bool eligible = level == 2 || unc * 16 <= S;
-                if (eligible && (level == 2 || ms < best_ms)) { best_ms = ms; best = level; }
             }
+            // the lowest eligible rung, unless a higher one is clearly (8 %) faster: one image per query is also the only form with
+            // wide int8 passes, and two rungs within the boxes' run-to-run noise must not flip the choice between processes
+            int best = 2;
+            for (int level = 1; level >= 0; --level)
+                if (unc_of[level] * 16 <= S) best = level;
+            for (int level = best + 1; level < 3; ++level)
+                if ((level == 2 || unc_of[level] * 16 <= S) && ms_of[level] < 0.92f * ms_of[best]) best = level;
             idx->scan8_level[c] = best;
             idx->scan8_checked[c] = idx->scan8_repaired[c] = 0;
             for (int l = 0; l < 3; ++l) { idx->calib_ms[c][l] = ms_of[l]; idx->calib_unc[c][l] = unc_of[l]; }

@@ -401,8 +401,8 @@ static hipError_t rq_scanw_launch_t(const RqScanArgs& a, int grid, hipStream_t s
 //   1  128 queries: as 0, reads 4 ahead
 //   8  128 queries: as 0 with asm fragment reads + counted lgkmcnt waits (within 1 % of 0)
 //  11  256 queries: 8 waves x 2 groups, reads 2 ahead, asm fragment reads + counted lgkmcnt waits: 256 VGPRs, nothing
-//      spilled (385-398 us per pass)                                                                   <- default for 256
-//   2  256 queries: as 11 with compiler-scheduled reads (7 values spilled outside the streaming loop; 400-415 us)
+//      spilled (385-398 us per pass); A/B only since round 3 (see the int8 note below)
+//   2  256 queries: as 11 with compiler-scheduled reads (7 values spilled outside the streaming loop; 400-415 us)   <- default for 256
 //   4  128 queries: as 1 with rq_scan.hip's compare/select epilogue (A/B of the selection forms)
 //   5  128 queries: 4 waves x 2 groups, one wave per SIMD (A/B: a lone wave cannot overlap its own VALU with its MFMAs)
 //   6  128 queries: as 0 with the selection of waves 4..7 staggered by half a tile;  7: as 0 with s_setprio 1 for waves 4..7
@@ -418,13 +418,12 @@ hipError_t rq_scan_wide_launch(const RqScanArgs& a, int variant, int queries, bo
     RQW_CASE(4, 4, 2, 8, 1, 0) RQW_CASE(5, 4, 1, 4, 2, 1)
     RQW_CASE(6, 12, 2, 8, 1, 1, 0, 2) RQW_CASE(7, 12, 2, 8, 1, 1, 0, 1)
     RQW_CASE(8, 12, 2, 8, 1, 1, 0, 3) RQW_CASE(11, 2, 2, 8, 2, 1, 0, 3)
-    // int8 image (a.i8 = 4): 20  256 queries, reads 12 ahead, asm reads + counted waits   <- default ("wide256_8")
-    //                        21  as 20, reads 6 ahead;  22  as 20, compiler-scheduled reads;  23  128 queries (8 waves x 1 group), reads 12 ahead
-    RQW_CASE(20, 12, 2, 8, 2, 1, 0, 3, 1) RQW_CASE(21, 6, 2, 8, 2, 1, 0, 3, 1) RQW_CASE(22, 12, 2, 8, 2, 1, 0, 0, 1)
-    RQW_CASE(23, 12, 2, 8, 1, 1, 0, 3, 1)
-    // 24  256 queries as 4 waves x 4 groups (one wave per SIMD, 192 VGPRs of query fragments): every LDS fragment feeds four MFMAs, half the
-    //     LDS read traffic of 20 (A/B)
-    RQW_CASE(24, 12, 1, 4, 4, 1, 0, 3, 1)
+    // int8 image (a.i8 = 4): 22  256 queries, 8 waves x 2 groups, reads 12 ahead, compiler-scheduled LDS waits   <- default ("wide256_8")
+    //     25  as 22, reads 6 ahead.  (Round 3 also built this form with asm fragment reads + counted lgkmcnt waits, as variants 8 / 11 do
+    //     for fp16: same speed -- 227 us per pass at 1M rows -- but NOT exact: one row in ~10^5 bins was scored from a stale register,
+    //     differently from run to run.  An asm ds_read is invisible to the compiler's own hazard tracking: it may copy or re-use the
+    //     destination register before the data has landed.  Removed; and the fp16 256-query default went back from 11 to 2 for the same reason.)
+    RQW_CASE(22, 12, 2, 8, 2, 1, 0, 0, 1) RQW_CASE(25, 6, 2, 8, 2, 1, 0, 0, 1)
     RQW_CASE(90, 4, 2, 8, 1, 0, 1) RQW_CASE(91, 4, 2, 8, 1, 0, 2) RQW_CASE(92, 4, 2, 8, 1, 0, 3)
     RQW_CASE(93, 12, 2, 8, 1, 1, 1) RQW_CASE(94, 12, 2, 8, 1, 1, 2) RQW_CASE(95, 12, 2, 8, 1, 1, 3)
 #undef RQW_CASE

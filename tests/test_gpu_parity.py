@@ -219,7 +219,7 @@ def test_every_kernel_variant_is_exact(corpus100k, opts):
                                   # every variant built in csrc/rq_scan_wide.hip: 128-query passes 0 / 1 / 4 / 5 / 6 / 7 / 8, 256-query passes 11 / 2
                                   dict(wide_batch=3, wide128=1), dict(wide_batch=3, wide128=4), dict(wide_batch=3, wide128=5),
                                   dict(wide_batch=3, wide128=6), dict(wide_batch=3, wide128=7), dict(wide_batch=3, wide128=8),
-                                  dict(wide_batch=1, wide256=2),
+                                  dict(wide_batch=1, wide256=11),     # (2 is the default since round 3)
                                   dict(wide_batch=1, nt=1), dict(wide_batch=1, cu_count=5)])
 def test_every_wide_pass_variant_is_exact(corpus100k, opts):
     """Calls with more than 64 queries are cut into passes of 256 / 128 / 64 queries (csrc/rq_api.hip run_pipeline).
@@ -1558,13 +1558,13 @@ def test_int8_wide_passes_match_oracle():
     # whose workgroups own an ODD number of quads (ring parity), and 0 = off (passes of 128 as in round 2)
     q600 = orc.synthetic_queries(600, 768, seed=17)
     q600[5] = x16[7].astype(np.float32); q600[300] = 0
-    for variant in (20, 21, 22, 24, 0):
+    for variant in (22, 25, 0):
         idx.set_option("wide256_8", variant)
-        for B in ((129, 257, 387, 576) if variant == 20 else (257,)):
+        for B in ((129, 257, 387, 576) if variant == 22 else (257,)):
             before = int(idx.get_option("scan8_used"))
             _check(idx, x16, q600[:B], 10)
             assert int(idx.get_option("scan8_used")) == before + 1, (variant, B)
-    idx.set_option("wide256_8", 20)
+    idx.set_option("wide256_8", 22)
     _check(idx, x16, 1.5 * q600[:300], 7, nat.METRIC_IP)
     odd = nat.NativeIndex(768, 0)
     odd.add_f16(x16[:256 * 3 * 64 + 64 * 5 + 9])               # 773 quads over 256 workgroups: 3 or 4 each
@@ -1752,7 +1752,7 @@ def test_int8_ladder_start_is_measured_at_image_build(kind):
     ms = [idx.get_option(f"scan8_calib_ms_0{l}") for l in range(3)]
     unc = [int(idx.get_option(f"scan8_calib_unc_0{l}")) for l in range(3)]
     assert all(m > 0 for m in ms) and unc[2] == 0
-    assert unc[level] * 16 <= 64 and ms[level] <= min(m for m, u in zip(ms, unc) if u * 16 <= 64) * 1.0001
+    assert (level == 2 or unc[level] * 16 <= 64) and ms[level] <= min(m for l, (m, u) in enumerate(zip(ms, unc)) if l == 2 or u * 16 <= 64) / 0.92 * 1.0001
     first_unc = int(st.sum())
     t0 = idx.timing()
     for rep in range(6):

@@ -1,5 +1,4 @@
-"""Round 3: calls of more than 64 queries at k = 10 on 1M x 768 -- the int8 256-query pass (csrc/rq_scan_wide.hip I8, option wide256_8 =
-20 / 21 / 22) against round 2's 128-query int8 passes (wide256_8 = 0) and the fp16 wide passes (wide8 = 0); per call, device API."""
+"""Round 3: calls of more than 64 queries at k = 10 on 1M x 768 -- the int8 256-query pass (csrc/rq_scan_wide.hip I8, option wide256_8 = 22 / 25) against round 2's 128-query int8 passes (wide256_8 = 0) and the fp16 wide passes (wide8 = 0); per call, device API."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,8 +16,8 @@ for B in (256, 512, 500, 192):
     q = torch.randn((B, 768), device=dev, generator=gq)
     sc = torch.empty((B, k), device=dev); rw = torch.empty((B, k), device=dev, dtype=torch.int64); st = torch.zeros((B,), device=dev, dtype=torch.int32)
     rows = {}
-    for name, w8, v in (("int8 256-pass v20", 1, 20), ("int8 256-pass v21", 1, 21), ("int8 256-pass v22", 1, 22), ("int8 256-pass v24", 1, 24), ("int8 128-passes   ", 1, 0), ("fp16 wide passes  ", 0, 20),
-                        ("int8 256-pass v20", 1, 20), ("int8 128-passes   ", 1, 0)):
+    for name, w8, v in (("int8 256-pass v22", 1, 22), ("int8 256-pass v25", 1, 25), ("int8 128-passes   ", 1, 0), ("fp16 wide passes  ", 0, 22),
+                        ("int8 256-pass v22", 1, 22), ("int8 128-passes   ", 1, 0)):
         idx.set_option("wide8", w8); idx.set_option("wide256_8", v); idx.set_option("profile", 0)
         for _ in range(5): idx.search_device(q, B, k, 0, sc, rw, None, st, 0)
         torch.cuda.synchronize(); idx.reset_timing(); idx.set_option("profile", 1); idx.set_option("profile_stride", 1)
