@@ -367,6 +367,7 @@ extern "C" double rq_get_option(const rq_index* idx, const char* name) {
             if (c >= 0 && c < 2 && l >= 0 && l < 3) return unc ? (double)idx->calib_unc[c][l] : (double)idx->calib_ms[c][l];
         }
     }
+    if (s == "repaired_queries") return (double)idx->repaired_total;   // queries rq_search_fixup_device (or the blocking rq_search) had to repair so far
     if (s == "scan8_used") return (double)idx->scan8_used;   // searches that scanned the int8 image
     if (s == "hints_used") return (double)idx->hints_used;   // searches that found their queries prepared by the launch before them
     if (s == "max_sub_rel") return idx->max_sub_rel;   // largest share of a row's norm that sits in fp16-subnormal elements
@@ -1023,6 +1024,7 @@ extern "C" int rq_search_fixup_device(rq_index* idx, const float* d_queries, int
     scan8_account(idx, k, B, (int)bad.size());
     if (bad.empty()) return 0;
     const int repaired = (int)bad.size();
+    idx->repaired_total += repaired;
     Workspace& w = idx->ctx[s].w[0];
     const int fb = (int)bad.size();
     if (fb > w.fix_bcap || k > w.fix_k) {

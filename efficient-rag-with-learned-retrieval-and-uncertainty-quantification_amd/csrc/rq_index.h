@@ -126,6 +126,7 @@ struct rq_index {
     float calib_ms[2][3] = {{0, 0, 0}, {0, 0, 0}};   // per class, per rung (one image / two images / fp16): ms of the 64-query sample search
     int calib_unc[2][3] = {{0, 0, 0}, {0, 0, 0}};    // ... and its uncertified queries
     bool last_use8 = false;        // the caller's last search scanned the int8 image (what rq_search_fixup_device's repairs are counted against)
+    int64_t repaired_total = 0;    // queries that came back uncertified and were repaired (any rung of the repair ladder)
     int64_t hints_used = 0;        // rq_search_hint_next_device: searches that skipped their preparation launch
     uint64_t scan_seq = 0;         // scan launches seen while profile = 1 (every profile_stride-th one is timed)
     // options

@@ -87,8 +87,13 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
     const int nloc = (int)((int64_t)(b + 1) * a.nquads / G) - q_lo;
     const int nst = nloc * SPQ;        // stages of this workgroup's quads
     const char* xb = (const char*)a.x;
-    char* norm_lds = rq_smem_w + 4 * STAGE_BYTES;                // [2 parities][64 row scales]
-    uint2* const stg = (uint2*)(norm_lds + 512);                 // [16 * QW * QG queries][SQ] finished records
+    // Row scales of a quad ride with the quad's first stage, which is issued TWO stages ahead.  fp16 (4 stages per quad): that is
+    // during the quad before -> 2 buffers.  int8 (2 stages per quad): that is near the end of the quad TWO before, whose last tile
+    // still reads its own scales -> 4 buffers (round 3: with 2, the slowest wave of a workgroup scored the last tile of quads 0 and 1
+    // with the scales of quads 2 and 3 now and then -- found because its bin maxima differed from the 128-query kernel's).
+    constexpr int NPAR = I8 ? 4 : 2;
+    char* norm_lds = rq_smem_w + 4 * STAGE_BYTES;                // [NPAR][64 row scales]
+    uint2* const stg = (uint2*)(norm_lds + 1024);                // [16 * QW * QG queries][SQ] finished records
 
     // stage gs = stage (gs % SPQ) of local quad (gs / SPQ) -> ring slot (gs & 3).  Stages are issued strictly in order, so the
     // source addresses are two running (wave-uniform) pointers instead of 64-bit multiplications per stage.
@@ -102,7 +107,7 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
             __builtin_amdgcn_global_load_lds((glb_ptr_w)(gnext + voff[i]), (lds_ptr_w)(l + i * 1024), 16, 0, AUX);
         gnext += STAGE_BYTES;
         if ((gs & (SPQ - 1)) == 0) {   // row scales of the quad (256 B); visible to all waves after wave 0's wait + a barrier
-            if (wave == 0) __builtin_amdgcn_global_load_lds((glb_ptr_w)nsnext, (lds_ptr_w)(norm_lds + (((gs / SPQ) & 1) << 8)), 4, 0, 0);
+            if (wave == 0) __builtin_amdgcn_global_load_lds((glb_ptr_w)nsnext, (lds_ptr_w)(norm_lds + (((gs / SPQ) & (NPAR - 1)) << 8)), 4, 0, 0);
             nsnext += RQ_QUAD_ROWS;
         }
     };
@@ -212,7 +217,7 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
         uint32_t ap[QG];                // rows (0..63) of the largest [7:0] and second largest [15:8]
 #pragma unroll
         for (int g = 0; g < QG; ++g) { m1[g] = NEG_INF; m2[g] = NEG_INF; m3[g] = NEG_INF; ap[g] = 0; }
-        const char* nrow = norm_lds + ((lq & 1) << 8) + kg * 16;
+        const char* nrow = norm_lds + ((lq & (NPAR - 1)) << 8) + kg * 16;
         // accumulators alternate between two register sets by tile parity: with PRIO == 2 the waves 4..7 of an 8-wave
         // workgroup run the selection of tile t after the first 12 MFMAs of tile t + 1 (tiles 0..2; tile 3's at the end of the
         // quad), so that of the two waves that share a SIMD one is in its VALU epilogue while the other feeds the matrix
@@ -371,7 +376,7 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
     }
 }
 
-static constexpr size_t rq_scanw_lds_bytes(int QW, int QG) { return (size_t)4 * 24576 + 512 + (size_t)16 * QW * QG * rqw_sq(QW, QG) * 8; }
+static constexpr size_t rq_scanw_lds_bytes(int QW, int QG) { return (size_t)4 * 24576 + 1024 + (size_t)16 * QW * QG * rqw_sq(QW, QG) * 8; }
 
 template <bool NT, int D, int OCC, int QW, int QG, int EPI, int DBG, int PRIO, int I8>
 __global__ __launch_bounds__(64 * QW, OCC) void rq_scanw_kernel(RqScanArgs a) {

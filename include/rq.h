@@ -159,7 +159,7 @@ int rq_merge_keys_device(const uint64_t* d_keys_in, int n_per_query, int B, int 
  * "poison_cand" (test hook: candidate lists are filled with 0xff..ff keys before every tail).
  * "scan8" = 1 measures where the ladder STARTS when the image is built (64 stored rows searched as queries through every rung, the
  *   fastest rung that certifies wins; "scan8_calibrated_rows", "scan8_calib_ms_<class><rung>", "scan8_calib_unc_<class><rung>" report it).
- * Read-only: "scan8_used" (searches that scanned the int8 image), "scan8_row_err" (worst row's relative int8 error, -1 = image
+ * Read-only: "repaired_queries" (queries that came back uncertified and were repaired, all rungs of the ladder), "scan8_used" (searches that scanned the int8 image), "scan8_row_err" (worst row's relative int8 error, -1 = image
  * not built), "scan8_level" (ladder position: class k <= 32 + 10 * class of larger k; 0 one image, 1 two images, 2 fp16 scan),
  * "scan8_suspended" (bit 0 / 1: that class is back at the fp16 scan), "hints_used" (searches that found their queries prepared, see rq_search_hint_next_device), "max_row_norm", "max_sub_rel" / "max_sub_abs" (largest share of a stored row that sits in fp16-subnormal elements,
  * which the matrix cores flush), "eps_cosine" / "eps_ip" (the certificate's bound including that term). */
