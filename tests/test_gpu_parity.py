@@ -1591,17 +1591,25 @@ def test_int8_ladder_counts_clean_calls_too():
     repaired queries IN TOTAL moved the class to the fp16 scan for good.  Now every checked query counts: 7 000 clean one-query calls
     with 280 queries that need repair among them (4 %, below the 1-in-16 rule) leave the level alone, results stay exact."""
     xg = orc.synthetic_corpus(30_000, 768, seed=61)
-    xc = orc.synthetic_corpus(30_000, 768, seed=62, clustered=True)     # 64 tight centroids: ~470 rows within the int8 bound of an on-topic query
-    x16 = np.concatenate([xg, xc], 0)
+    xc = orc.synthetic_corpus(60_000, 768, seed=62, clustered=True)     # 64 tight centroids of ~940 rows: inside one, the k-th approximate
+    x16 = np.concatenate([xg, xc], 0)                                   # score overestimates the exact one by more than the threshold's slack
     idx = nat.NativeIndex(768, 0)
     idx.add_f16(x16)
     idx.set_option("scan8", 2)
-    clean = xg[::300][:100].astype(np.float32) + 0.2 * orc.synthetic_queries(100, 768, seed=63)    # near Gaussian rows: certified at once
-    dirty = xc[::997][:4].astype(np.float32) + 0.05 * orc.synthetic_queries(4, 768, seed=64)      # inside a cluster: candidate lists overflow
-    rep0 = int(idx.get_option("repaired_queries"))
-    for i in range(4):
-        _check(idx, x16, dirty[i:i + 1], 10)
-    assert int(idx.get_option("repaired_queries")) == rep0 + 4, "the on-topic queries are expected to need the repair ladder"
+
+    def repaired_by(qv):
+        idx.set_option("scan8", 2)                        # (fresh ladder windows: the probing itself must not move the level)
+        before = int(idx.get_option("repaired_queries"))
+        _check(idx, x16, qv[None, :], 10)
+        return int(idx.get_option("repaired_queries")) - before
+    # queries that need the repair ladder (stored rows of the clusters) and queries that never do (near Gaussian rows), picked by trying
+    cand_dirty = xc[5::461][:96].astype(np.float32)
+    dirty = np.stack([v for v in cand_dirty if repaired_by(v) == 1][:4])
+    assert dirty.shape[0] == 4, "expected on-topic queries of the clustered part to need the repair ladder"
+    cand_clean = xg[::200][:150].astype(np.float32) + 0.2 * orc.synthetic_queries(150, 768, seed=63)
+    clean = np.stack([v for v in cand_clean if repaired_by(v) == 0][:100])
+    assert clean.shape[0] == 100
+    base = int(idx.get_option("repaired_queries"))
     idx.set_option("scan8", 2)                            # start over: levels and windows
     assert idx.get_option("scan8_level") == 10.0
     for rep in range(70):
@@ -1610,7 +1618,7 @@ def test_int8_ladder_counts_clean_calls_too():
         for i in range(4):
             idx.search(dirty[i:i + 1], 10)
     assert idx.get_option("scan8_level") == 10.0, "4 % repaired queries must not move the k <= 32 class off the one-image scan"
-    assert int(idx.get_option("repaired_queries")) == rep0 + 4 + 280      # (only the dirty ones were repaired, every time)
+    assert int(idx.get_option("repaired_queries")) == base + 280          # (only the dirty ones were repaired, every time)
     _check(idx, x16, clean[:64], 10)
     # ... while a stream of nothing but failing one-query calls still escalates
     for rep in range(150):

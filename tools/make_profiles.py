@@ -44,8 +44,8 @@ for logname in ("bench2", "bench20", "prof_bench", "prof_bench_1s"):
             d = json.loads(lines[-1])
             print(logname, "value", round(d["value"]), "ms/step", round(d["ms_per_step"], 4), "scan avg us", round(d["roofline"]["avg_launch_us"], 1), "frac", round(d["roofline"]["frac"], 3))
 
-# The default bench launches two instantiations of the fused kernel: rq_scan_tail_kernel<true, 8, 2> (the int8 scan, the timed
-# region) and <true, 8, 1> (the fp16 scan, the comparison loop after it).  Each gets its own summary.
+# The default bench launches two instantiations of the fused kernel at 1M rows: rq_scan_tail_kernel<true, 8, 1> (the fp16 rows: the
+# timed region, `value`, since round 3) and <true, 8, 2> (the int8 image: the `int8_scan` leg after it).  Each gets its own summary.
 VARIANTS = (("rq_scan_tail_kernel<true, 8, 2>", "8", 768, "SQ_INSTS_VALU_MFMA_MOPS_I8", "int8 image of the fp16 shard, i8 matrix cores"),
             ("rq_scan_tail_kernel<true, 8, 1>", "", 1536, "SQ_INSTS_VALU_MFMA_MOPS_F16", "fp16 rows, f16 matrix cores"))
 

@@ -15,6 +15,6 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -- pyt
 # matrix-core counters (north star: "rocprof HBM GB/s and MFMA utilisation against gfx950 peak"), their own pass
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc_mfma -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/pmc_mfma.log 2>&1
 cd $R
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench20.log 2>gpurun_out/bench20.err
+python bench.py --steps 20 --warmup 5 > gpurun_out/bench20.log 2>gpurun_out/bench20.err
 find gpurun_out/prof_bench gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_mfma -type f ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" -delete
 ls -R gpurun_out/prof_bench | head
