@@ -27,6 +27,15 @@ if ks:
         w.writerows(keep)
     print("kernel stats:", [(r["Name"][:40], r["Calls"], round(float(r["AverageNs"]) / 1e3, 1)) for r in keep[:6]])
 
+ks8 = first("prof_bench8/*/*kernel_stats.csv")
+if ks8:
+    rows = list(csv.DictReader(open(ks8)))
+    with open(os.path.join(out, f"{tag}_bench_int8_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows([r for r in rows if "rq_" in r["Name"]])
+    print("int8 run kernel stats:", [(r["Name"][:40], r["Calls"], round(float(r["AverageNs"]) / 1e3, 1)) for r in rows if "rq_" in r["Name"]][:4])
+
 ks1 = first("prof_bench_1s/*/*kernel_stats.csv")
 if ks1:
     rows = list(csv.DictReader(open(ks1)))
@@ -35,7 +44,7 @@ if ks1:
         w.writeheader()
         w.writerows([r for r in rows if "rq_" in r["Name"]])
     print("single-stream kernel stats:", [(r["Name"][:40], r["Calls"], round(float(r["AverageNs"]) / 1e3, 1)) for r in rows if "rq_" in r["Name"]][:4])
-for logname in ("bench2", "bench20", "prof_bench", "prof_bench_1s"):
+for logname in ("bench2", "bench20", "prof_bench", "prof_bench8", "prof_bench_1s"):
     lp = os.path.join(ROOT, "gpurun_out", logname + ".log")
     if os.path.exists(lp):
         lines = [l for l in open(lp, errors="replace").read().splitlines() if l.startswith('{"metric"')]
@@ -44,23 +53,26 @@ for logname in ("bench2", "bench20", "prof_bench", "prof_bench_1s"):
             d = json.loads(lines[-1])
             print(logname, "value", round(d["value"]), "ms/step", round(d["ms_per_step"], 4), "scan avg us", round(d["roofline"]["avg_launch_us"], 1), "frac", round(d["roofline"]["frac"], 3))
 
-# The default bench launches two instantiations of the fused kernel at 1M rows: rq_scan_tail_kernel<true, 8, 1> (the fp16 rows: the
-# timed region, `value`, since round 3) and <true, 8, 2> (the int8 image: the `int8_scan` leg after it).  Each gets its own summary.
+# Two instantiations of the fused kernel at 1M rows: rq_scan_tail_kernel<true, 8, 1> (the fp16 rows: bench.py's timed region, `value`, since
+# round 3) and <true, 8, 2> (the int8 image: bench.py --scan int8, the `int8_scan` leg of the default run).  Since round 3 each is profiled by
+# a run of its own WITHOUT the extra legs (tools/run_profiles.sh: prof_bench / prof_bench8, pmc_*/ pmc_*8), so that the per-kernel averages are
+# those of the 1M-row Gaussian loop alone and not mixed with the structured-corpus legs that launch the same kernels.
 VARIANTS = (("rq_scan_tail_kernel<true, 8, 2>", "8", 768, "SQ_INSTS_VALU_MFMA_MOPS_I8", "int8 image of the fp16 shard, i8 matrix cores"),
             ("rq_scan_tail_kernel<true, 8, 1>", "", 1536, "SQ_INSTS_VALU_MFMA_MOPS_F16", "fp16 rows, f16 matrix cores"))
 
 def kernel_avg_us(sel):
-    if not ks:
+    src = ks8 if (", 2>" in sel and ks8) else ks        # each operand from the run that timed it alone
+    if not src:
         return None
-    for r in csv.DictReader(open(ks)):
+    for r in csv.DictReader(open(src)):
         if sel in r["Name"]:
             return float(r["AverageNs"]) / 1e3
     return None
 
-mf = first("pmc_mfma/*/*counter_collection.csv")
 for sel, suffix, row_bytes, mops, what in VARIANTS:
+    mf = first(f"pmc_mfma{suffix}/*/*counter_collection.csv")
     if not mf:
-        break
+        continue
     acc = {}
     for r in csv.DictReader(open(mf)):
         if sel in r["Kernel_Name"]:
@@ -87,7 +99,7 @@ for sel, suffix, row_bytes, mops, what in VARIANTS:
 for sel, suffix, row_bytes, mops, what in VARIANTS:
     pmc = {}
     for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-        f = first(f"{name}/*/*counter_collection.csv")
+        f = first(f"{name}{suffix}/*/*counter_collection.csv")
         if not f:
             continue
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and sel in r["Kernel_Name"]]
