@@ -288,14 +288,16 @@ class BM25Index:
         self.__dict__["_csr_cache"] = c
         return c
 
-    def search_batch(self, queries: Sequence[str], top_k: int = 10, *, n_threads: int = 0, use_native: Optional[bool] = None
-                     ) -> List[List[Tuple[str, float]]]:
-        """`[self.search(q, top_k) for q in queries]`, scored as one job: librq_bm25.so (include/rq_bm25.h) walks the posting lists
-        of every query on the host cores -- term at a time, one float64 accumulator per thread, the contributions added in query
-        order (the same additions as get_scores: identical bits), top-k by a heap with the tie rule of _select_topk.  Without
-        the library (`use_native=False`, or it is not built) the same arrays are scored with numpy, one query at a time."""
-        if self.bm25 is None or not self.doc_ids or top_k <= 0:
-            return [[] for _ in queries]
+    def search_batch_rows(self, queries: Sequence[str], top_k: int = 10, *, n_threads: int = 0, use_native: Optional[bool] = None
+                          ) -> Tuple[np.ndarray, np.ndarray]:
+        """The selection of `search` for a whole batch, in ROW space: (rows int32 [B][top_k], -1 padded; scores float64 [B][top_k]).
+        librq_bm25.so (include/rq_bm25.h) walks the posting lists of every query on the host cores -- term at a time, one float64
+        accumulator per thread, the contributions added in query order (the same additions as get_scores: identical bits), top-k by a
+        heap with the tie rule of _select_topk.  Without the library (`use_native=False`, or it is not built) the same arrays are
+        scored with numpy, one query at a time."""
+        B, k = len(queries), max(int(top_k), 1)
+        if self.bm25 is None or not self.doc_ids or top_k <= 0 or B == 0:
+            return np.full((B, k), -1, np.int32), np.zeros((B, k))
         c = self._csr()
         tid = c["tid"]
         q_tok: List[int] = []
@@ -306,30 +308,41 @@ class BM25Index:
                 if j is not None:
                     q_tok.append(j)
             q_ptr.append(len(q_tok))
-        native = c["handle"] is not None if use_native is None else (use_native and c["handle"] is not None)
         if use_native and c["handle"] is None:
             raise _native.RqError("librq_bm25.so is not built: `make -C csrc` (or use_native=False for the numpy path)")
-        B, k = len(q_ptr) - 1, int(top_k)
+        native = c["handle"] is not None if use_native is None else (use_native and c["handle"] is not None)
         if native:
-            out_rows, out_scores = _native.bm25_topk(c["handle"], np.asarray(q_ptr, np.int64), np.asarray(q_tok, np.int32), B, k, n_threads)
-            ids = np.empty(len(self.doc_ids), dtype=object)
-            cache = self.__dict__.get("_ids_np")
-            if cache is None or len(cache) != len(self.doc_ids):
-                ids[:] = self.doc_ids
-                cache = self.__dict__["_ids_np"] = ids
-            idl = cache[np.where(out_rows >= 0, out_rows, 0)].tolist()
-            scl = out_scores.tolist()
-            have = (out_rows >= 0).sum(axis=1).tolist()
-            return [list(zip(idl[b][:have[b]], scl[b][:have[b]])) for b in range(B)]
+            return _native.bm25_topk(c["handle"], np.asarray(q_ptr, np.int64), np.asarray(q_tok, np.int32), B, k, n_threads)
         indptr, rows, contrib = c["indptr"], c["rows"], c["contrib"]
-        res = []
+        out_rows, out_scores = np.full((B, k), -1, np.int32), np.zeros((B, k))
         for b in range(B):
             scores = np.zeros(len(self.doc_ids))
             for j in q_tok[q_ptr[b]: q_ptr[b + 1]]:
                 lo, hi = indptr[j], indptr[j + 1]
                 scores[rows[lo:hi]] += contrib[lo:hi]
-            res.append([(self.doc_ids[i], float(scores[i])) for i in self._select_topk(scores, k).tolist()])
-        return res
+            sel = self._select_topk(scores, k)
+            out_rows[b, :len(sel)] = sel
+            out_scores[b, :len(sel)] = scores[sel]
+        return out_rows, out_scores
+
+    def _ids_array(self) -> np.ndarray:
+        cache = self.__dict__.get("_ids_np")
+        if cache is None or len(cache) != len(self.doc_ids):
+            cache = np.empty(len(self.doc_ids), dtype=object)
+            cache[:] = self.doc_ids
+            self.__dict__["_ids_np"] = cache
+        return cache
+
+    def search_batch(self, queries: Sequence[str], top_k: int = 10, *, n_threads: int = 0, use_native: Optional[bool] = None
+                     ) -> List[List[Tuple[str, float]]]:
+        """`[self.search(q, top_k) for q in queries]`, scored as one job (search_batch_rows)."""
+        if self.bm25 is None or not self.doc_ids or top_k <= 0:
+            return [[] for _ in queries]
+        out_rows, out_scores = self.search_batch_rows(queries, top_k, n_threads=n_threads, use_native=use_native)
+        idl = self._ids_array()[np.where(out_rows >= 0, out_rows, 0)].tolist()
+        scl = out_scores.tolist()
+        have = (out_rows >= 0).sum(axis=1).tolist()
+        return [list(zip(idl[b][:have[b]], scl[b][:have[b]])) for b in range(len(have))]
 
     def _drop_csr(self) -> None:
         c = self.__dict__.pop("_csr_cache", None)
@@ -687,8 +700,10 @@ class DenseIndex:
         if cache is None or len(cache[0]) != len(self._ids):
             ids = np.empty(len(self._ids), dtype=object)
             ids[:] = self._ids
-            texts = np.empty(len(self._texts), dtype=object)
-            texts[:] = self._texts
+            texts = None                       # a collection that stores no passage text (add_vectors without texts): nothing to gather
+            if any(self._texts):
+                texts = np.empty(len(self._texts), dtype=object)
+                texts[:] = self._texts
             cache = self.__dict__["_idtext_np"] = (ids, texts)
         return cache
 
@@ -698,7 +713,8 @@ class DenseIndex:
         ok = rows >= 0
         all_ok = bool(ok.all())
         safe = rows if all_ok else np.where(ok, rows, 0)
-        idl, txl, scl = ids[safe].tolist(), texts[safe].tolist(), scores.astype(np.float64).tolist()
+        idl, scl = ids[safe].tolist(), scores.astype(np.float64).tolist()
+        txl = texts[safe].tolist() if texts is not None else [[""] * rows.shape[1]] * rows.shape[0]
         if all_ok:
             return [list(zip(i, s, t)) for i, s, t in zip(idl, scl, txl)]
         okl = ok.tolist()
@@ -717,15 +733,20 @@ class DenseIndex:
     def search_device_vectors(self, d_vectors, top_k: int = 10) -> List[List[Tuple[str, float, str]]]:
         """Queries that are already in HBM (a CUDA tensor [B][dim] fp32, e.g. `NomicBertEmbedder.embed_device`): searched where they
         are (rq_search_device on torch's current stream), repaired if a certificate failed, ONE device-to-host copy of rows + scores."""
-        import torch
         B = int(d_vectors.shape[0])
         if self._index is None or len(self._ids) == 0 or top_k <= 0 or B == 0:
             return [[] for _ in range(B)]
+        return self._assemble(*self._search_device_rows(d_vectors, top_k))
+
+    def _search_device_rows(self, d_vectors, top_k: int) -> Tuple[np.ndarray, np.ndarray]:
+        """(scores float32 [B][k], rows int64 [B][k], -1 padded), k = min(top_k, rows of the index)"""
+        import torch
+        B = int(d_vectors.shape[0])
         if int(d_vectors.shape[1]) != self.dim:
             raise ValueError(f"query dimension {int(d_vectors.shape[1])} does not match the index ({self.dim})")
-        if not hasattr(self._index, "search_device") or len(getattr(self._index, "devices", [0])) > 1:
-            return self.search_vectors(d_vectors.float().cpu().numpy(), top_k)       # multi-device parent: host-buffer calls only
         k = min(int(top_k), len(self._ids), _native.MAX_K)
+        if not hasattr(self._index, "search_device") or len(getattr(self._index, "devices", [0])) > 1:
+            return self._index.search(d_vectors.float().cpu().numpy(), k, self.metric)       # multi-device parent: host-buffer calls only
         dev = d_vectors.device
         q = d_vectors.to(torch.float32).contiguous()
         buf = self.__dict__.get("_dev_out")
@@ -751,7 +772,24 @@ class DenseIndex:
         host = pinned.numpy()
         rows = host[: 2 * B * k].view(np.int64).reshape(B, k)
         scores = host[2 * B * k: 3 * B * k].view(np.float32).reshape(B, k)
-        return self._assemble(scores, rows)
+        return scores, rows
+
+    def search_rows_batch(self, queries: Sequence[str], top_k: int = 10) -> Tuple[np.ndarray, np.ndarray]:
+        """`search_batch` without the (doc_id, score, text) tuples: (scores float32 [B][k], rows int64 [B][k], -1 padded; row r is
+        `self._ids[r]`), k = min(top_k, len(self)).  What HybridRetriever's batched fusion consumes (extension)."""
+        B = len(queries)
+        if self._index is None or len(self._ids) == 0 or top_k <= 0 or B == 0:
+            return np.zeros((B, 0), np.float32), np.zeros((B, 0), np.int64)
+        if hasattr(self.embedder, "embed_device"):
+            try:
+                d_q = self.embedder.embed_device(list(queries))
+            except Exception as e:
+                logger.error(f"Device embedding failed ({e}); falling back to the host path")
+                d_q = None
+            if d_q is not None:
+                return self._search_device_rows(d_q, top_k)
+        k = min(int(top_k), len(self._ids), _native.MAX_K)
+        return self._index.search(self._embed_matrix(list(queries)), k, self.metric)
 
     def search_batch(self, queries: Sequence[str], top_k: int = 10) -> List[List[Tuple[str, float, str]]]:
         if not queries:
@@ -920,6 +958,19 @@ class HybridRetriever:
     def hybrid_search_batch(self, queries: Sequence[str], top_k: int = 10, retrieval_pool_size: int = 50) -> List[List[RetrievalResult]]:
         """All dense pools from one GPU batch, all BM25 pools from one pass over the posting lists on the host cores (librq_bm25.so);
         fusion per query."""
+        fused = self._fuse_batch_rows(queries, top_k, retrieval_pool_size)
+        if fused is not None:
+            ids, _, b, de, hy, count = fused
+            idl, bl, dl, hl = ids.tolist(), b.tolist(), de.tolist(), hy.tolist()
+            out = []
+            for q in range(len(queries)):
+                res = []
+                for i in range(int(count[q])):
+                    doc = self.documents[idl[q][i]]
+                    res.append(RetrievalResult(doc_id=doc.id, text=doc.text, bm25_score=bl[q][i], dense_score=dl[q][i], hybrid_score=hl[q][i],
+                                               title=doc.title, metadata=doc.metadata))
+                out.append(res)
+            return out
         dense, sparse = self._pools_batch(queries, retrieval_pool_size)
         return [self._fuse(sparse[i], dense[i], top_k) for i in range(len(queries))]
 
@@ -954,8 +1005,16 @@ class HybridRetriever:
         return self._router_arrays(self.hybrid_search(query, top_k=num_passages, retrieval_pool_size=retrieval_pool_size), num_passages)
 
     def get_scores_for_router_batch(self, queries: Sequence[str], num_passages: int = 20, *, retrieval_pool_size: int = 50):
-        """`[get_scores_for_router(q, ...) for q in queries]` with the pools of the whole batch computed at once and the four padded
-        lists assembled straight from the fused columns (no RetrievalResult objects in between)."""
+        """`[get_scores_for_router(q, ...) for q in queries]` with the pools of the whole batch computed at once.  When both sides are
+        this module's own indexes the fusion itself runs on the whole batch in row space (`_fuse_batch_rows`); otherwise per query on the
+        fused columns (no RetrievalResult objects in between)."""
+        fused = self._fuse_batch_rows(queries, num_passages, retrieval_pool_size)
+        if fused is not None:
+            ids, texts, b, de, _, count = fused
+            pad_mask = np.arange(num_passages)[None, :] >= count[:, None]
+            ids[pad_mask] = ""
+            texts[pad_mask] = ""
+            return list(zip(b.tolist(), de.tolist(), ids.tolist(), texts.tolist()))
         dense, sparse = self._pools_batch(queries, retrieval_pool_size)
         documents = self.documents
         out = []
@@ -967,6 +1026,75 @@ class HybridRetriever:
                 b = b + [0.0] * pad; de = de + [0.0] * pad; ids = ids + [""] * pad; texts = texts + [""] * pad
             out.append((b, de, ids, texts))
         return out
+
+    # ---- batched fusion in row space (extension; configs[4]: 500 questions x two pools of 100) ------------------------------------
+    def _key_space(self):
+        """One integer key per document either index can return: BM25 row r -> r, dense row j -> the BM25 row of the same id if BM25
+        holds it, else n_bm25 + j.  Per key: the id, the text `self.documents` holds for it, and whether `self.documents` knows it at all
+        (reference :491-493 skips ids it does not).  Rebuilt when any of the three stores has grown."""
+        bm, dn = self.bm25_index, self.dense_index
+        stamp = (len(bm.doc_ids), len(dn._ids), len(self.documents))
+        c = self.__dict__.get("_keys_cache")
+        if c is not None and c["stamp"] == stamp:
+            return c
+        nb = len(bm.doc_ids)
+        row_of = {d: i for i, d in enumerate(bm.doc_ids)}
+        dense_key = np.fromiter((row_of.get(d, nb + j) for j, d in enumerate(dn._ids)), np.int64, len(dn._ids))
+        all_ids = list(bm.doc_ids) + list(dn._ids)
+        ids = np.empty(len(all_ids), dtype=object)
+        ids[:] = all_ids
+        docs = self.documents
+        known = np.fromiter((d in docs for d in all_ids), np.bool_, len(all_ids))
+        texts = np.empty(len(all_ids), dtype=object)
+        texts[:] = [docs[d].text if d in docs else "" for d in all_ids]
+        c = self.__dict__["_keys_cache"] = {"stamp": stamp, "nb": nb, "dense_key": dense_key, "ids": ids, "texts": texts, "known": known}
+        return c
+
+    def _fuse_batch_rows(self, queries: Sequence[str], top_k: int, retrieval_pool_size: int):
+        """`_fuse_columns` for every query of the batch at once, on integer keys: same candidates (union of both pools in first-seen
+        order -- BM25 pool, then dense pool -- ids unknown to `self.documents` dropped), same float64 arithmetic (`max(...) or 1` over all
+        candidates, hybrid = (b/max_b + d/max_d)/2), same stable descending sort, first top_k.  Returns (ids [B][top_k] object, texts,
+        bm25 scores, dense scores, hybrid scores, count [B]) -- entries beyond count[b] are padding -- or None when one of the two sides
+        is not this module's own index class (then the per-query path runs)."""
+        bm, dn = self.bm25_index, self.dense_index
+        if not (isinstance(bm, BM25Index) and isinstance(dn, DenseIndex)) or len(queries) == 0 or top_k <= 0:
+            return None
+        B = len(queries)
+        ks = self._key_space()
+        sp_rows, sp_scores = bm.search_batch_rows(list(queries), retrieval_pool_size)
+        de_scores, de_rows = dn.search_rows_batch(list(queries), retrieval_pool_size)
+        K1, K2 = sp_rows.shape[1], de_rows.shape[1]
+        sp_keys = sp_rows.astype(np.int64)
+        de_keys = np.where(de_rows >= 0, ks["dense_key"][np.where(de_rows >= 0, de_rows, 0)], -1) if K2 else np.zeros((B, 0), np.int64)
+        keys = np.concatenate([sp_keys, de_keys], axis=1)
+        bsc = np.concatenate([sp_scores, np.zeros((B, K2))], axis=1)
+        dsc = np.concatenate([np.zeros((B, K1)), de_scores.astype(np.float64)], axis=1)
+        valid = keys >= 0
+        valid &= ks["known"][np.where(valid, keys, 0)]
+        # a document in both pools: its dense score moves to the BM25 entry (first seen), the dense entry goes
+        order = np.argsort(keys, axis=1, kind="stable")
+        sk = np.take_along_axis(keys, order, 1)
+        r, j = np.nonzero((sk[:, 1:] == sk[:, :-1]) & (sk[:, 1:] >= 0))
+        first, second = order[r, j], order[r, j + 1]
+        dsc[r, first] = dsc[r, second]
+        valid[r, second] = False
+        neg_inf = -np.inf
+        max_b = np.where(valid, bsc, neg_inf).max(axis=1, initial=neg_inf)
+        max_d = np.where(valid, dsc, neg_inf).max(axis=1, initial=neg_inf)
+        max_b = np.where((max_b == 0) | ~np.isfinite(max_b), 1.0, max_b)          # `max(...) or 1` (a row without candidates: anything)
+        max_d = np.where((max_d == 0) | ~np.isfinite(max_d), 1.0, max_d)
+        h = (bsc / max_b[:, None] + dsc / max_d[:, None]) / 2
+        sort_key = np.where(valid, -np.where(h == 0, 0.0, h), np.inf)            # `key = hybrid or 0`, descending, stable; dropped entries last
+        sel = np.argsort(sort_key, axis=1, kind="stable")[:, :top_k]
+        if sel.shape[1] < top_k:                                                  # pools smaller than top_k: pad the columns
+            sel = np.concatenate([sel, np.zeros((B, top_k - sel.shape[1]), np.int64)], axis=1)
+        count = np.minimum(valid.sum(axis=1), top_k)
+        live = np.arange(top_k)[None, :] < count[:, None]
+        out_keys = np.where(live, np.take_along_axis(keys, sel, 1), 0)
+        b = np.where(live, np.take_along_axis(bsc, sel, 1), 0.0)
+        de = np.where(live, np.take_along_axis(dsc, sel, 1), 0.0)
+        hy = np.where(live, np.take_along_axis(h, sel, 1), 0.0)
+        return ks["ids"][out_keys], ks["texts"][out_keys], b, de, hy, count
 
     def close(self) -> None:
         """Write the BM25 snapshot if documents were added since the last one (extension; the reference has no close)."""

@@ -377,3 +377,75 @@ def test_bm25_batch_equals_per_query_equals_oracle_with_ties():
     b.add_documents([si.Document(id="new", text=texts[7])])
     assert b.search_batch([texts[7]], 3) == [b.search(texts[7], 3)] and b.search(texts[7], 1)[0][0] == "new"
     assert si.BM25Index().search_batch(["x"], 3) == [[]]
+
+
+class _StubNative:
+    """Host stand-in for _native.NativeIndex in CPU tests of the Python seam: brute-force inner product / cosine in float64 with the
+    canonical order.  Test scaffolding (the product has no CPU backend); only what DenseIndex.from_native / search_rows_batch touch."""
+    device, devices = 0, [0]
+
+    def __init__(self, x):
+        self.x = np.asarray(x, np.float64)
+        self.dim = self.x.shape[1]
+
+    def __len__(self):
+        return self.x.shape[0]
+
+    def search(self, q, k, metric=0):
+        q = np.atleast_2d(np.asarray(q, np.float64))
+        sc = q @ self.x.T
+        if metric == 0:
+            sc = sc / (np.linalg.norm(q, axis=1)[:, None] * np.linalg.norm(self.x, axis=1)[None, :] + 1e-30)
+        sc = sc.astype(np.float32)
+        rows = np.full((q.shape[0], k), -1, np.int64); out = np.zeros((q.shape[0], k), np.float32)
+        for b in range(q.shape[0]):
+            o = np.lexsort((np.arange(len(self)), -sc[b].astype(np.float64)))[:k]
+            rows[b, :len(o)] = o; out[b, :len(o)] = sc[b, o]
+        return out, rows
+
+
+@pytest.mark.parametrize("metric", ["cosine", "ip"])
+def test_batched_fusion_in_row_space_equals_the_per_query_path(tmp_path, metric):
+    """HybridRetriever.get_scores_for_router_batch / hybrid_search_batch fuse the whole batch on integer keys (`_fuse_batch_rows`); the
+    result must be the per-query path's, value for value and in the same order: documents in both pools, only in BM25, only in the dense
+    index (not indexed by BM25), dense ids `self.documents` does not know (dropped, reference :491-493), questions without any BM25 hit,
+    pools smaller than top_k (padding), exactly tied hybrid scores (stable order), and -- inner product with a negated query -- all-negative
+    dense scores, which invert the order through `max(...) or 1` (reference :506-511)."""
+    from rag_uq_amd.embedders import RandomProjectionEmbedder
+    rng = np.random.default_rng(3)
+    vocab = [f"w{i}" for i in range(40)]
+    texts = [" ".join(rng.choice(vocab, size=6)) for _ in range(120)]
+    texts[30:34] = [texts[5]] * 4                                          # duplicates: tied BM25 AND dense scores
+    docs = [si.Document(id=f"p{i}", text=t, title=f"T{i}") for i, t in enumerate(texts)]
+    emb = RandomProjectionEmbedder(16)
+
+    class NegEmb:                                                           # every dense score negative under the inner product
+        dim = 16
+        def embed(self, ts): return -np.abs(emb.embed(ts))
+    vec = emb.embed(texts)
+    if metric == "ip":
+        vec = np.abs(vec)
+    extra_ids = [f"ghost{i}" for i in range(5)] + [f"donly{i}" for i in range(6)]      # dense-only rows: 5 unknown to the store, 6 known
+    extra_vec = emb.embed([texts[i] + " w1" for i in range(11)])
+    if metric == "ip":
+        extra_vec = np.abs(extra_vec)
+    dense = si.DenseIndex.from_native(_StubNative(np.concatenate([vec, extra_vec])), [d.id for d in docs] + extra_ids,
+                                      embedder=NegEmb() if metric == "ip" else emb, metric=metric)
+    r = si.HybridRetriever(bm25_persist_path=str(tmp_path / "b.pkl"), chroma_persist_path=str(tmp_path / "c"), dense_index=dense)
+    r.bm25_index.add_documents(docs[:100])                                  # p100..p119 are not in BM25
+    for d in docs:
+        r.documents[d.id] = d
+    for i in range(6):
+        r.documents[f"donly{i}"] = si.Document(id=f"donly{i}", text=f"dense only {i}")
+    queries = [" ".join(rng.choice(vocab, size=4)) for _ in range(30)] + [texts[5], "nothing known here", texts[110], ""]
+    for num, pool in ((10, 50), (20, 7), (100, 100), (3, 1)):
+        want = [r.get_scores_for_router(q, num_passages=num, retrieval_pool_size=pool) for q in queries]
+        got = r.get_scores_for_router_batch(queries, num_passages=num, retrieval_pool_size=pool)
+        assert r._fuse_batch_rows(queries, num, pool) is not None           # (the row-space path really ran)
+        assert [tuple(g) for g in got] == [tuple(w) for w in want], (num, pool)
+        assert r.hybrid_search_batch(queries, top_k=num, retrieval_pool_size=pool) == [r.hybrid_search(q, top_k=num, retrieval_pool_size=pool) for q in queries]
+    flat = [i for q in queries for i in r.get_scores_for_router(q, 100, retrieval_pool_size=100)[2]]
+    assert any(i.startswith("donly") for i in flat) and not any(i.startswith("ghost") for i in flat)
+    # the key space follows the stores: a document added later is found by the batch path too
+    r.bm25_index.add_documents([docs[100]])
+    assert r.get_scores_for_router_batch([texts[100]], 5) == [r.get_scores_for_router(texts[100], 5)]
