@@ -313,6 +313,7 @@ extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     else if (s == "wide8") idx->wide8 = (int)v != 0;   // calls of more than 64 queries may use 128-query passes over the int8 image
     else if (s == "scan8_split") { if (v < -1 || v > 1) return set_err(RQ_EINVAL, "scan8_split must be -1, 0 or 1"); idx->scan8_split = (int)v; scan8_reset_levels(idx); }   // see run_pipeline
     else if (s == "thr_mult8") { if (!(v >= 1.05 && v <= 2.25)) return set_err(RQ_EINVAL, "thr_mult8 %g outside 1.05..2.25", v); idx->thr_mult8 = v; }
+    else if (s == "exact_mfma") idx->exact_mfma = (int)v != 0;   // A/B: 0 = the exact scan of a whole shard re-scores bin by bin and query by query (rq_rescore_kernel, rounds 1-2)
     else if (s == "bin_bound") idx->bin_bound = (int)v != 0;     // A/B: 0 = every bin is tested with the shard's worst row error (round 2)
     else if (s == "tail_local") idx->tail_local = (int)v != 0;   // A/B: 0 = every re-scored row's key goes to the query's global list
     else if (s == "use_hint") idx->use_hint = (int)v != 0;   // 0: rq_search_hint_next_device is ignored (A/B of the folded query preparation)
@@ -913,7 +914,8 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     ra.x = idx->x; ra.q32 = w.q32; ra.qnorm64 = w.qn; ra.rownorm64 = idx->rownorm64;
     ra.binkeys = exact ? nullptr : w.binkeys; ra.binkeys_stride = m; ra.nb = nb; ra.metric = metric;
     ra.n_rows = idx->n; ra.cand = w.cand;
-    HIPCHK(rq_rescore_launch(ra, B, s));
+    if (exact && idx->exact_mfma) HIPCHK(rq_exact_scan_launch(ra, B, idx->cu_count, s));   // the whole shard: fp64 contraction on the matrix cores
+    else HIPCHK(rq_rescore_launch(ra, B, s));
     RqFinalArgs fa;
     fa.cand = w.cand; fa.ncand = (int)ncand; fa.binkeys = w.binkeys; fa.binkeys_stride = m; fa.nb = nb; fa.nbins = exact ? nb : nbins;
     fa.qnorm64 = w.qn; fa.metric = metric; fa.eps = scan_eps(idx, metric);

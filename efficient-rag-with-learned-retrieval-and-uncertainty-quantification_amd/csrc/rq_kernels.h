@@ -84,6 +84,9 @@ struct RqRescoreArgs {
     uint64_t* cand;            // [B][nb*64]
 };
 hipError_t rq_rescore_launch(const RqRescoreArgs& a, int B, hipStream_t stream);
+// Exact mode only (a.binkeys == nullptr, every bin of the shard): the same keys from a dense fp64 contraction on the matrix cores
+// (v_mfma_f64_16x16x4_f64, rq_exact.hip): a 16-row tile is read once for 64 queries instead of once per query.
+hipError_t rq_exact_scan_launch(const RqRescoreArgs& a, int B, int cu_count, hipStream_t stream);
 
 // Pass 4: top-k of the candidates, certificate, outputs.
 struct RqFinalArgs {

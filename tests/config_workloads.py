@@ -222,9 +222,17 @@ def run_config4(n_passages: int = 50_000, n_questions: int = 500, pool: int = 10
     for lo in range(0, n_passages, 5000):
         r.add_documents(docs[lo: lo + 5000], batch_size=5000)
     t_build = time.perf_counter() - t0
+    # per corpus state, not per batch: the CSR form of the posting lists (+ the librq_bm25 handle) and the key space of the batched fusion
+    # are built by the first batched call after an add; timed on their own here, then every later batch runs against them
+    t0 = time.perf_counter()
+    r.get_scores_for_router_batch(questions[:8], num_passages=num_passages, retrieval_pool_size=pool)
+    t_first = time.perf_counter() - t0
     t0 = time.perf_counter()
     gpu_arrays = r.get_scores_for_router_batch(questions, num_passages=num_passages, retrieval_pool_size=pool)
     t_gpu = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    r.bm25_index.search_batch_rows(questions, pool)
+    t_bm25 = time.perf_counter() - t0
     t0 = time.perf_counter()
     dense_only = dense.search_batch(questions, pool)
     t_dense = time.perf_counter() - t0
@@ -244,7 +252,7 @@ def run_config4(n_passages: int = 50_000, n_questions: int = 500, pool: int = 10
             "recall_at_10_dense_only": float(np.mean([ro.recall_at_k([d for d, _, _ in l], [g], 10) for l, g in zip(dense_only, gold)])),
             "id_lists_identical": bool(gpu_lists == cpu_lists),
             "router_inputs_identical": bool(all(a[2] == b[2] and np.allclose(a[1], b[1], atol=1e-6) and a[0] == b[0] for a, b in zip(gpu_arrays, cpu_arrays))),
-            "index_build_s": t_build, "hybrid_batch_ms": t_gpu * 1e3, "dense_top100_batch_ms": t_dense * 1e3,
+            "index_build_s": t_build, "first_batched_call_ms": t_first * 1e3, "bm25_top100_batch_ms": t_bm25 * 1e3, "hybrid_batch_ms": t_gpu * 1e3, "dense_top100_batch_ms": t_dense * 1e3,
             "questions_per_s_hybrid": n_questions / t_gpu}
 
 
