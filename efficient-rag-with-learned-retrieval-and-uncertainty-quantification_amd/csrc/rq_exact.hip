@@ -71,22 +71,18 @@ __global__ __launch_bounds__(256, 1) void rq_exact_scan_kernel(RqRescoreArgs a, 
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)(float)cur[j][e], (double)bq[e], acc, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);      // conversions stay with their 8 MFMAs: hoisting all 384 of them spilled 94 registers
         }
-        // D[row = 4 kq + i][query = c16]: this lane's four rows are consecutive -> 32 contiguous bytes of its query's key array
-        const int64_t row0 = t * 16 + 4 * kq;
-        uint64_t key[4];
+        // D of the fp64 16x16x4 form: register i of lane (c16, kq) is D[row = 4 i + kq][query = c16] (NOT 4 kq + i as for the fp32 /
+        // int32 16x16 forms): for a fixed i the four lanes that share a query hold four consecutive rows -> 32 contiguous bytes
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int64_t row = row0 + i;
-            key[i] = 0;
+            const int64_t row = t * 16 + 4 * i + kq;
+            uint64_t key = 0;
             if (row < a.n_rows) {
                 double s = acc[i];
                 if (a.metric == 0) s = acc[i] / (qn * a.rownorm64[row] + 1e-30);
-                key[i] = rq_make_key(rq_sanitize((float)s), (uint32_t)row);
+                key = rq_make_key(rq_sanitize((float)s), (uint32_t)row);
             }
-        }
-        if (live_q) {
-            *(ulonglong2*)(out + row0) = make_ulonglong2(key[0], key[1]);
-            *(ulonglong2*)(out + row0 + 2) = make_ulonglong2(key[2], key[3]);
+            if (live_q) out[row] = key;
         }
         if (tn < ntiles) {
 #pragma unroll
@@ -95,9 +91,7 @@ __global__ __launch_bounds__(256, 1) void rq_exact_scan_kernel(RqRescoreArgs a, 
     }
     // the slots between the last tile and the end of the last bin (rows_alloc is a multiple of 64, tiles are 16 rows): empty keys
     if (blockIdx.x == 0 && par == 0 && live_q) {
-        for (int64_t row = ntiles * 16 + 4 * kq; row < rows_alloc; row += 16)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) out[row + i] = 0;
+        for (int64_t row = ntiles * 16 + kq; row < rows_alloc; row += 4) out[row] = 0;
     }
 }
 
