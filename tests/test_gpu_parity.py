@@ -1778,3 +1778,63 @@ def test_int8_ladder_start_is_measured_at_image_build(kind):
     idx.set_option("scan8", 2)                                                    # "always": no measurement, round 2's start levels
     assert idx.get_option("scan8_level") == 10.0 and idx.get_option("scan8_calibrated_rows") == 0
     idx.close()
+
+
+@pytest.mark.parametrize("scan8", [0, 2])
+def test_search_train_equals_single_calls(scan8):
+    """rq_search_train_device (round 3: what bench.py enqueues between two all-gathers at N > 1) == the same searches made one
+    rq_search_device call at a time: 23 batches over two caller streams with the fused tails (pipeline 2), keys with a row offset,
+    the next train announced by the last launches (hints used), a ragged B, then a second train on the same streams; every batch
+    equals the oracle.  Bad arguments are refused before anything is enqueued."""
+    import torch
+    dev = torch.device("cuda:0")
+    n, B, k, off = 70_000, 48, 10, 5_000_000
+    x16 = orc.synthetic_corpus(n, 768, seed=111)
+    idx = nat.NativeIndex(768, 0)
+    idx.add_f16(x16)
+    idx.set_row_offset(off)
+    idx.set_option("pipeline", 2)
+    idx.set_option("scan8", scan8)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    nb = 23
+    qs = [orc.synthetic_queries(B, 768, seed=2000 + i) for i in range(nb + 2)]
+    dq = [torch.from_numpy(q).to(dev) for q in qs]
+    mk = lambda: dict(sc=[torch.full((B, k), -7.0, device=dev) for _ in range(nb)], rw=[torch.full((B, k), -7, device=dev, dtype=torch.int64) for _ in range(nb)],
+                      ky=[torch.zeros((B, k), device=dev, dtype=torch.int64) for _ in range(nb)], st=[torch.full((B,), 9, device=dev, dtype=torch.int32) for _ in range(nb)])
+    a, b = mk(), mk()
+    torch.cuda.synchronize()
+    train = idx.make_train(dq[:nb], a["sc"], a["rw"], a["ky"], a["st"], [s.cuda_stream for s in streams], dq[nb:nb + 2])
+    h0 = int(idx.get_option("hints_used"))
+    idx.search_train_device(train, B, k)
+    # the two announced batches are searched next on the same streams: their queries were prepared by the train's last launches
+    tail_out = []
+    for j in range(2):
+        sc = torch.empty((B, k), device=dev); rw = torch.empty((B, k), device=dev, dtype=torch.int64); st = torch.zeros((B,), device=dev, dtype=torch.int32)
+        idx.search_device(dq[nb + j], B, k, 0, sc, rw, None, st, streams[(nb + j) % 2].cuda_stream)
+        tail_out.append((sc, rw, st))
+    for s in streams:
+        idx.search_flush_device(s.cuda_stream)
+    torch.cuda.synchronize()
+    assert int(idx.get_option("hints_used")) - h0 >= nb - 2 + 2          # every batch but the first of each stream found its queries prepared
+    idx.set_option("pipeline", 0)                                           # the same searches, one call at a time, no hints, plain pipeline
+    for i in range(nb):
+        idx.search_device(dq[i], B, k, 0, b["sc"][i], b["rw"][i], b["ky"][i], b["st"][i], 0)
+    torch.cuda.synchronize()
+    for i in range(nb):
+        assert int(a["st"][i].abs().sum()) == 0 and int(b["st"][i].abs().sum()) == 0
+        for name in ("sc", "rw", "ky"):
+            assert torch.equal(a[name][i], b[name][i]), (i, name)
+    for i in (0, 1, nb - 1):
+        gs, gr = orc.dense_topk(qs[i], x16, k, row_offset=off)
+        assert np.array_equal(a["rw"][i].cpu().numpy(), gr) and float(np.abs(a["sc"][i].cpu().numpy() - gs).max()) <= SCORE_TOL
+    for j in range(2):
+        gs, gr = orc.dense_topk(qs[nb + j], x16, k, row_offset=off)
+        assert np.array_equal(tail_out[j][1].cpu().numpy(), gr) and int(tail_out[j][2].sum()) == 0
+    # keys carry the global row: unpack one
+    from rag_uq_amd import distributed as d
+    ks, kr = d.unpack_keys(a["ky"][3].cpu().numpy().view(np.uint64))
+    assert np.array_equal(kr, a["rw"][3].cpu().numpy())
+    bad = idx.make_train(dq[:2], a["sc"][:2], a["rw"][:2], None, [a["st"][0], None], [streams[0].cuda_stream])
+    with pytest.raises(nat.RqError):
+        idx.search_train_device(bad, B, k)
+    idx.close()
