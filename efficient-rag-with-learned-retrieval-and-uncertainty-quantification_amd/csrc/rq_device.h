@@ -88,6 +88,13 @@ __device__ __forceinline__ float rq_pos_score(float acc_times_scale, uint32_t po
     const float sc = __builtin_amdgcn_fmed3f(acc_times_scale, -3.4028234664e38f, 3.4028234664e38f);
     return __uint_as_float((__float_as_uint(sc) & 0xffffffc0u) | pos);
 }
+// The same without the clamp, for scores that are finite or NaN by construction (the int8 scan: an exact int32 sum times a finite row
+// scale, NaN only from the pad rows' NaN scale): a NaN needs no special care -- v_max_f32 returns the other operand and v_med3_f32 with a
+// NaN operand returns the MINIMUM of the other two, so rq_insert3 leaves a sorted triple m1 >= m2 >= m3 exactly as it was (the position
+// bits keep a quiet NaN a quiet NaN).  One VALU less per score where instruction issue is the bound (rq_scan_wide.hip I8).
+__device__ __forceinline__ float rq_pos_score_finite(float acc_times_scale, uint32_t pos) {
+    return __uint_as_float((__float_as_uint(acc_times_scale) & 0xffffffc0u) | pos);
+}
 // value part times a positive scale, position bits kept (one more truncation of the 6 low bits: part of the error bound)
 __device__ __forceinline__ float rq_scale_pos(float x, float scale) {
     const uint32_t b = __float_as_uint(x);

@@ -294,8 +294,8 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
                 for (int g = 0; g < QG; ++g)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const float raw = I8 ? (float)iacc[g][i] : acc[g][i];
-                        rq_insert3(m1[g], m2[g], m3[g], rq_pos_score(raw * nv[i], (uint32_t)(t * 16 + i)));
+                        if (I8) rq_insert3(m1[g], m2[g], m3[g], rq_pos_score_finite((float)iacc[g][i] * nv[i], (uint32_t)(t * 16 + i)));
+                        else rq_insert3(m1[g], m2[g], m3[g], rq_pos_score(acc[g][i] * nv[i], (uint32_t)(t * 16 + i)));
                     }
             }
             if (s == KS - 1 && DBG != 1 && EPI == 0) {
