@@ -93,6 +93,12 @@ def main() -> None:
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run, one rank per GPU "
                          "(python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N)")
+    # RQ_BENCH_BACKEND=gloo (rehearsal only): several ranks on ONE GPU -- RCCL refuses two ranks on one device -- exchanging their keys through
+    # host memory.  Everything else is the N > 1 path unchanged (row shards, per-rank searches, merge, the exact-scan cross-check); timings
+    # of such a run mean nothing, its results (`ids_match_exact_fp64_scan`, `ranks_seen`) do.
+    backend = os.environ.get("RQ_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # RQ_BENCH_FORCE_COMM=1 exercises the all-gather + merge path on a single rank (rehearsal on a 1-GPU box)
@@ -103,8 +109,26 @@ def main() -> None:
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         ranks_seen = dist.get_world_size()
+
+    def all_gather_keys(dst, src):
+        """dst [world, ...] <- every rank's src (RCCL over xGMI; through host memory in the gloo rehearsal)"""
+        if backend != "gloo":
+            dist.all_gather_into_tensor(dst, src)
+            return
+        torch.cuda.current_stream().synchronize()
+        parts = [torch.empty(src.shape, dtype=src.dtype) for _ in range(world)]
+        dist.all_gather(parts, src.cpu())
+        dst.copy_(torch.stack(parts).to(dst.device))
+
+    def all_reduce_scalar(value, op=None, dtype=None):
+        t = torch.tensor([value], device="cpu" if backend == "gloo" else dev, dtype=dtype or torch.int64)
+        dist.all_reduce(t, op=op or dist.ReduceOp.SUM)
+        return t.item()
 
     n_total, k, B = args.rows, args.k, BATCH
     n_chunks = (n_total + CHUNK_ROWS - 1) // CHUNK_ROWS
@@ -161,7 +185,7 @@ def main() -> None:
             for s in streams:
                 comm_stream.wait_stream(s)
             with torch.cuda.stream(comm_stream):
-                dist.all_gather_into_tensor(self.gathered[r], self.ring[r])
+                all_gather_keys(self.gathered[r], self.ring[r])
                 merged_in = self.gathered[r].permute(1, 2, 0, 3).contiguous()   # [G][B][world][k]
                 nat.merge_keys_device(merged_in, world * k, GATHER_EVERY * B, k, self.m_scores, self.m_rows, None, comm_stream.cuda_stream)
                 pending["ev"][r] = comm_stream.record_event()
@@ -220,16 +244,14 @@ def main() -> None:
                 o = self.slots[j]
                 fixed += idx.search_fixup_device(self.qs[j], B, k, nat.METRIC_COSINE, o["scores"], o["rows"], o["keys"], o["status"], 0)
             if use_comm:
-                t = torch.tensor([fixed], device=dev, dtype=torch.int64)
-                dist.all_reduce(t)
-                if int(t.item()) > 0:
+                if int(all_reduce_scalar(fixed)) > 0:
                     # rare: some shard repaired a query after its keys were gathered -> redo those batches synchronously
                     one = torch.zeros((world, B, k), device=dev, dtype=torch.int64)
                     for j in range(nslots):
                         o = self.slots[j]
                         idx.search_device(self.qs[j], B, k, nat.METRIC_COSINE, o["scores"], o["rows"], o["keys"], o["status"], 0)
                         idx.search_fixup_device(self.qs[j], B, k, nat.METRIC_COSINE, o["scores"], o["rows"], o["keys"], o["status"], 0)
-                        dist.all_gather_into_tensor(one, o["keys"])
+                        all_gather_keys(one, o["keys"])
                         nat.merge_keys_device(one.permute(1, 0, 2).contiguous(), world * k, B, k, o["scores"], o["rows"], None, 0)
             return fixed
 
@@ -286,9 +308,7 @@ def main() -> None:
             r = {"host_phases": {"enqueue_all_steps_us": (t_enq - t0) * 1e6, "flush_copy_sync_us": (t_fin - t_enq) * 1e6,
                                  "status_check_and_final_sync_us": (t0 + elapsed - t_fin) * 1e6}}
             if use_comm:
-                t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                elapsed = float(t.item())
+                elapsed = float(all_reduce_scalar(elapsed, dist.ReduceOp.MAX, torch.float64))
             r["elapsed"], r["fixed"], r["steps"] = elapsed, fixed, steps
             r["timing"] = idx.timing()
             r["int8"] = int(idx.get_option("scan8_used")) - scan8_before == steps      # every timed search scanned the int8 image
@@ -421,7 +441,7 @@ def main() -> None:
                    "scan": SCAN_TEXT[int8_scan], "scan_option": args.scan,
                    "rows_per_gpu": n_local, "streams": len(streams), "pipeline": args.pipeline, "next_batch_hint": use_hint, "gather_every": GATHER_EVERY if use_comm else 0,
                    "enqueue": "rq_search_train_device (one library call per gather period)" if loop.trains is not None else "rq_search_device per step",
-                   "parallelism": f"row-shard x{world}", "ranks_seen": ranks_seen},
+                   "parallelism": f"row-shard x{world}", "ranks_seen": ranks_seen, "exchange": ("RCCL all-gather" if backend != "gloo" else "gloo through host memory (one-GPU rehearsal)") if use_comm else "none"},
         "roofline": roofline_of(main_r, iso, n_local, live_events),
         "repaired_queries": main_r["fixed"],
         "host_phases": main_r["host_phases"],
@@ -541,7 +561,7 @@ def main() -> None:
         idx.search_device(queries[0], B, k, nat.METRIC_COSINE, o["scores"], o["rows"], o["keys"], o["status"], 0)
         idx.search_fixup_device(queries[0], B, k, nat.METRIC_COSINE, o["scores"], o["rows"], o["keys"], o["status"], 0)
         allk = torch.zeros((world, B, k), device=dev, dtype=torch.int64)
-        dist.all_gather_into_tensor(allk, o["keys"])
+        all_gather_keys(allk, o["keys"])
         g_scores = torch.empty((B, k), device=dev)
         g_rows = torch.empty((B, k), device=dev, dtype=torch.int64)
         nat.merge_keys_device(allk.permute(1, 0, 2).contiguous(), world * k, B, k, g_scores, g_rows, None, 0)
@@ -552,7 +572,7 @@ def main() -> None:
         if n_local:
             idx.search_device(queries[0][:nchk].contiguous(), nchk, k, nat.METRIC_COSINE, e_sc, e_rw, e_ky, e_st, 0)
         oall = torch.zeros((world, nchk, k), device=dev, dtype=torch.int64)
-        dist.all_gather_into_tensor(oall, e_ky)
+        all_gather_keys(oall, e_ky)
         ms, mr = rqd.merge_keys_host(oall.permute(1, 0, 2).reshape(nchk, world * k).cpu().numpy().view(np.uint64), k)
         got_r = g_rows[:nchk].cpu().numpy()
         out["ids_match_exact_fp64_scan"] = bool((got_r == mr).all())
