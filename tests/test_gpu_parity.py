@@ -824,7 +824,7 @@ def test_long_structured_sweep():
     for case in range(ncases):
         big = case < int(os.environ.get("RQ_LONG_SWEEP_BIG", "0"))       # the first few cases at the headline size
         n = 1_000_000 if big else int(rng.choice([9_000, 20_011, 65_536, 100_003, 180_000]))
-        B = int(rng.choice([1, 7, 64, 64, 100, 130, 260]))
+        B = int(rng.choice([1, 7, 64, 64, 100, 130, 260, 300, 520]))
         k = int(rng.choice([1, 10, 10, 50, 100, 128]))
         metric = int(rng.integers(0, 2))
         kind = str(rng.choice(["gauss", "docs", "clusters", "dups"]))
@@ -862,6 +862,9 @@ def test_long_structured_sweep():
         idx.set_option("scan8", int(rng.choice([0, 1, 2, 2, 2])))        # the int8 image: never / size rule / always,
         idx.set_option("scan8_split", int(rng.choice([-1, -1, 0, 1])))    #   one or two images per query, 128-query passes
         idx.set_option("wide8", int(rng.choice([1, 1, 0])))
+        idx.set_option("wide256_8", int(rng.choice([22, 22, 25, 0])))     # round 3: 256-query int8 passes (two read-ahead distances) / passes of 128
+        idx.set_option("bin_bound", int(rng.choice([1, 1, 0])))           #   per-bin quantisation bound in the tail
+        idx.set_option("exact_mfma", int(rng.choice([1, 1, 0])))          #   exact scan on the fp64 matrix cores (repairs that reach the last rung)
         try:
             if mode == 0:
                 _check(idx, x16, q, k, metric)
