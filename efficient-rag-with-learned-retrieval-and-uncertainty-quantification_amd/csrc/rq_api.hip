@@ -295,7 +295,7 @@ extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     else if (s == "wide256") { if (v < 0 || v > 92) return set_err(RQ_EINVAL, "wide256: a 256-query variant of csrc/rq_scan_wide.hip"); idx->wide256 = (int)v; }
     else if (s == "kstage") { if (v != 1 && v != 2) return set_err(RQ_EINVAL, "kstage must be 1 or 2"); idx->kstage = (int)v; }
     else if (s == "prefetch") { if (v != 1 && v != 4 && v != 6 && v != 12) return set_err(RQ_EINVAL, "prefetch must be 1, 4, 6 or 12"); idx->prefetch = (int)v; }
-    else if (s == "wg_per_cu") { if (v < 1 || v > 8) return set_err(RQ_EINVAL, "wg_per_cu must be 1..8"); idx->wg_per_cu = (int)v; }
+    else if (s == "wg_per_cu") { if (v < 0 || v > 8) return set_err(RQ_EINVAL, "wg_per_cu must be 1..8 (0: back to the library's rule)"); idx->wg_auto = v == 0; idx->wg_per_cu = v == 0 ? 2 : (int)v; }
     else if (s == "nt") idx->nt = (int)v;
     else if (s == "cu_count") { if (v < 1 || v > 1024) return set_err(RQ_EINVAL, "cu_count must be 1..1024"); idx->cu_count = (int)v; }   // test hook: shrinks the scan grid
     else if (s == "slack_bins") idx->slack_bins = (int)v;
@@ -794,7 +794,17 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     }
     // one scan grid for every pass of the call (the tail reads nwg partition maxima per query): the widest pass decides
     // every fp16 pass of more than 64 queries, and the int8 256-query pass, runs one 512-thread workgroup per CU
-    const int wg_cu = (qb0 > 64 && (!use8 || qb0 == 256)) ? 1 : idx->wg_per_cu;
+    int wg_cu = (qb0 > 64 && (!use8 || qb0 == 256)) ? 1 : idx->wg_per_cu;
+    // Small int8 shards searched from SEVERAL caller streams (the per-rank shape of a multi-GPU run: 125k rows, two streams): two fused
+    // launches are resident at once, so ONE scan workgroup per CU and launch already keeps two per CU streaming, and each lives twice as
+    // long -- the prologue (48 KB of query fragments + the ring fill) is paid half as often.  Measured, two streams + exchange, us per
+    // batch with 2 / 1 workgroups per CU: 125k rows 24.2 / 20.5, 250k rows 32.5 / 31.4; the fp16 rows are at the streaming rate either way
+    // (28.7 / 29.7): int8 only, below 8 quads per workgroup, and only while another stream has a fused tail pending.
+    if (fused && use8 && idx->wg_auto && wg_cu == 2 && (int64_t)nquads < (int64_t)16 * idx->cu_count) {
+        bool other_stream_busy = false;
+        for (auto& kv : idx->ctx) other_stream_busy = other_stream_busy || (kv.first != s && kv.second.fused_pending);
+        if (other_stream_busy) wg_cu = 1;
+    }
     const int grid = (int)std::min<int64_t>(std::min<int64_t>(nquads, RQ_WGMAX_STRIDE), (int64_t)idx->cu_count * wg_cu);
     if (!exact) {
         // non-temporal loads only for shards that cannot stay in the 256 MiB Infinity Cache between two scans

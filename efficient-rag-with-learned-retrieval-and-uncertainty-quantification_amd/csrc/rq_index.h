@@ -125,6 +125,7 @@ struct rq_index {
     int64_t calib_rows = 0;        // rows of the shard when the ladder's start levels were last measured (0 = not yet)
     float calib_ms[2][3] = {{0, 0, 0}, {0, 0, 0}};   // per class, per rung (one image / two images / fp16): ms of the 64-query sample search
     int calib_unc[2][3] = {{0, 0, 0}, {0, 0, 0}};    // ... and its uncertified queries
+    bool wg_auto = true;           // scan workgroups per CU by the library's rule (option "wg_per_cu" pins it)
     bool last_use8 = false;        // the caller's last search scanned the int8 image (what rq_search_fixup_device's repairs are counted against)
     int64_t repaired_total = 0;    // queries that came back uncertified and were repaired (any rung of the repair ladder)
     int64_t hints_used = 0;        // rq_search_hint_next_device: searches that skipped their preparation launch
