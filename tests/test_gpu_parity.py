@@ -943,7 +943,7 @@ def test_no_device_memory_leak_over_index_lifetimes():
 
 def test_option_validation_and_status_codes():
     idx = nat.NativeIndex(8, 0)
-    for name, bad in [("ring", 9), ("bin_tiles", 4), ("wg_per_cu", 0), ("prefetch", 5), ("kstage", 3), ("nonsense", 1)]:
+    for name, bad in [("ring", 9), ("bin_tiles", 4), ("wg_per_cu", 9), ("prefetch", 5), ("kstage", 3), ("nonsense", 1)]:
         with pytest.raises(nat.RqError):
             idx.set_option(name, bad)
     idx.set_option("ring", 6); assert idx.get_option("ring") == 6
