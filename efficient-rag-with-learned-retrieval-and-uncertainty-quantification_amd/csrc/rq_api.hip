@@ -314,6 +314,7 @@ extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     else if (s == "scan8_split") { if (v < -1 || v > 1) return set_err(RQ_EINVAL, "scan8_split must be -1, 0 or 1"); idx->scan8_split = (int)v; scan8_reset_levels(idx); }   // see run_pipeline
     else if (s == "thr_mult8") { if (!(v >= 1.05 && v <= 2.25)) return set_err(RQ_EINVAL, "thr_mult8 %g outside 1.05..2.25", v); idx->thr_mult8 = v; }
     else if (s == "exact_mfma") idx->exact_mfma = (int)v != 0;   // A/B: 0 = the exact scan of a whole shard re-scores bin by bin and query by query (rq_rescore_kernel, rounds 1-2)
+    else if (s == "fused_nv") idx->fused_nv = (int)v;   // development: bins per riding tail workgroup (0 = the launcher's rule, 1 / 4 / 8 x 512)
     else if (s == "bin_bound") idx->bin_bound = (int)v != 0;     // A/B: 0 = every bin is tested with the shard's worst row error (round 2)
     else if (s == "tail_local") idx->tail_local = (int)v != 0;   // A/B: 0 = every re-scored row's key goes to the query's global list
     else if (s == "use_hint") idx->use_hint = (int)v != 0;   // 0: rq_search_hint_next_device is ignored (A/B of the folded query preparation)
@@ -520,7 +521,9 @@ static int scan8_calibrate(rq_index* idx, hipStream_t s) {
         idx->calib_rows = idx->n;
         return RQ_OK;
     };
+    const int level_before[2] = {idx->scan8_level[0], idx->scan8_level[1]};
     rc = body();
+    if (rc != RQ_OK) { idx->scan8_level[0] = level_before[0]; idx->scan8_level[1] = level_before[1]; }   // (a failed measurement leaves no trial rung behind)
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     void* p[] = {d_q, d_sc, d_rw, d_st};
@@ -894,6 +897,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             ta.out_scores = d_scores; ta.out_rows = d_rows; ta.out_keys = d_keys; ta.out_status = d_status;
             ta.dbg = idx->dbg_stamps;
             ta.stop_after = idx->tail_stop;
+            ta.fused_nv = idx->fused_nv;
             if (idx->tail_stop) w.counters_zero = false;   // a truncated tail does not reset its counters
             if (fused) {
                 // the tail runs with the NEXT scan launch (or at the flush): it reads the workspace's own copy of the

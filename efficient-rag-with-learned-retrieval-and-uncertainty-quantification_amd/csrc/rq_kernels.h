@@ -135,6 +135,7 @@ struct RqTailArgs {
     float thr_slack;                               //   certifies; less = fewer candidates, the rare query is repaired (rq_tail_body.h)
     unsigned long long* dbg;                       // development: per-workgroup (start, end) wall-clock stamps of the fused launch, or null
     int stop_after;                                // development: 0 = full kernel, 1..4 = return after phase A..D
+    int fused_nv;                                  // development: 0 = the launcher's rule, 1 / 4 / 8 = 512 / 2048 / 4096 bins per riding tail workgroup
 };
 // workgroups [0, scan_grid) run the scan `sa`, the next ones the tail `ta` of an EARLIER batch, the last pa.nslots the query
 // preparation `pa` of a LATER batch
