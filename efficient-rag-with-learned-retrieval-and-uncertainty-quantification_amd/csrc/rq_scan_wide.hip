@@ -376,6 +376,169 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// 256 queries per pass over the int8 image on v_mfma_i32_32x32x32_i8: a wave owns 32 queries as ONE operand.  Same ring, DMA, acquire
+// points and record staging as the I8 form of rq_scanw_body (a stage = 32 rows of 768 B = exactly one 32-row A block, 24 k-steps of 32
+// bytes; a quad = 2 stages; 4 row-scale buffers), but per wave and quad: half the MFMA instructions (each does twice the work), ONE
+// cross-lane merge round instead of four (the two lanes l, l + 32 that share a query), one record instead of two -- the VALU issue the
+// 16x16 form is bound by.  Result layout of the 32x32 forms: register i of lane l is D[row = 8 (i / 4) + 4 (l / 32) + i % 4]
+// [query = l % 32].
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef int rq_int16 __attribute__((ext_vector_type(16)));
+
+template <bool NT, int D>
+__device__ __forceinline__ void rq_scanw32_body(const RqScanArgs& a, const int b, const int G) {
+    static_assert(D >= 2 && D <= 12 && 48 % D == 0, "prefetch distance");
+    constexpr int QW = 8, ROWB = RQ_DPAD, KS = 24, FQ = 48, CH = ROWB / 16, STAGE_BYTES = 24576, SPQ = 2;
+    constexpr int DPW = 24 / QW, VM_KEEP = DPW, SQ = 16, NPAR = 4;
+    constexpr unsigned AUX = NT ? 2u : 0u;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r32 = lane & 31;         // corpus row inside the 32-row block (A operand), query inside the wave (B operand, result column)
+    const int h = lane >> 5;           // k half of the operands / row sub-block of the result
+
+    unsigned voff[DPW];
+#pragma unroll
+    for (int i = 0; i < DPW; ++i) {
+        const int p = 64 * (wave * DPW + i) + lane;
+        const int r = p / CH, cp = p % CH;
+        voff[i] = (unsigned)(r * ROWB + ((cp ^ (r & 15)) << 4));
+    }
+    const int q_lo = (int)((int64_t)b * a.nquads / G);
+    const int nloc = (int)((int64_t)(b + 1) * a.nquads / G) - q_lo;
+    const int nst = nloc * SPQ;
+    const char* xb = (const char*)a.x;
+    char* norm_lds = rq_smem_w + 4 * STAGE_BYTES;
+    uint2* const stg = (uint2*)(norm_lds + 1024);
+    const char* gnext = xb + (int64_t)q_lo * (RQ_QUAD_ROWS * ROWB);
+    const float* nsnext = a.row_scale + (int64_t)q_lo * RQ_QUAD_ROWS + lane;
+    auto issue = [&](int gs) {
+        const int t = gs & 3;
+        char* l = rq_smem_w + t * STAGE_BYTES + (wave * DPW) * 1024;
+#pragma unroll
+        for (int i = 0; i < DPW; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_w)(gnext + voff[i]), (lds_ptr_w)(l + i * 1024), 16, 0, AUX);
+        gnext += STAGE_BYTES;
+        if ((gs & (SPQ - 1)) == 0) {
+            if (wave == 0) __builtin_amdgcn_global_load_lds((glb_ptr_w)nsnext, (lds_ptr_w)(norm_lds + (((gs / SPQ) & (NPAR - 1)) << 8)), 4, 0, 0);
+            nsnext += RQ_QUAD_ROWS;
+        }
+    };
+    auto acquire = [&](int gs) {
+        if (gs + 1 < nst) rqw_wait_vmcnt<VM_KEEP>(); else rqw_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (gs + 2 < nst) issue(gs + 2);
+    };
+    issue(0);
+    if (nst > 1) issue(1);
+
+    // B operand: q8[32 wave + r32][32 s + 16 h .. + 15] of k-step s
+    rq_int4 qf[KS];
+    {
+        const rq_int4* qsrc = (const rq_int4*)((const char*)a.qh + (size_t)(32 * wave + r32) * ROWB + 16 * h);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) qf[s] = qsrc[2 * s];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qf[s]));
+    }
+    const float qsc = a.qscale[32 * wave + r32];
+    // A operand of k-step s: logical chunk 2 s + h of row r32, stored at chunk (2 s + h) ^ (r32 & 15): the low chunk bit is (h ^ r15 & 1),
+    // bits 1..3 are ((s & 7) ^ (r15 >> 1)) -> one per-lane base per (s & 7), the rest of s is an immediate ((s & ~7) * 32 bytes)
+    const int r15 = r32 & 15;
+    unsigned lbase[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+        lbase[m] = (unsigned)(size_t)(lds_ptr_w)rq_smem_w + (unsigned)(r32 * ROWB + (((h ^ (r15 & 1)) + 2 * (m ^ (r15 >> 1))) << 4));
+    // tile t (= stage t of the quad) sits in ring slot 2 * (quad parity) + t
+    auto frag = [&](int t, int s, unsigned par_off) -> rq_int4 {
+        return *(const rq_int4*)((const char*)(__attribute__((address_space(3))) const char*)(size_t)(lbase[s & 7] + par_off) + t * STAGE_BYTES + ((s & ~7) << 5));
+    };
+    float wmax = -__builtin_huge_valf();
+    const float NEG_INF = -__builtin_huge_valf();
+    int nq_valid = a.nq_valid, wgmax_stride = a.wgmax_stride;
+    int64_t bins_stride = a.bins_stride;
+    uint2* bins_p = a.bins;
+    float* wgmax_p = a.wgmax;
+    asm volatile("" : "+s"(nq_valid), "+s"(wgmax_stride), "+s"(bins_stride), "+s"(bins_p), "+s"(wgmax_p));
+    auto flush = [&](int quad0, int count) {
+        constexpr int QPI = 64 / SQ;
+#pragma unroll 1
+        for (int i = 0; i < 32 / QPI; ++i) {
+            const int ql = 32 * wave + QPI * i + lane / SQ, j = lane & (SQ - 1);
+            if (j < count && ql < nq_valid) bins_p[(int64_t)ql * bins_stride + quad0 + j] = stg[ql * SQ + j];
+        }
+    };
+
+    rq_int4 av[D];
+    acquire(0);
+#pragma unroll
+    for (int f = 0; f < D; ++f) av[f] = frag(f / KS, f % KS, 0u);
+
+    for (int lq = 0; lq < nloc; ++lq) {
+        const bool more = lq + 1 < nloc;
+        const unsigned pc = (unsigned)((lq & 1) * 2 * STAGE_BYTES), pn = (unsigned)(((lq + 1) & 1) * 2 * STAGE_BYTES);
+        float m1 = NEG_INF, m2 = NEG_INF, m3 = NEG_INF;
+        const char* nrow = norm_lds + ((lq & (NPAR - 1)) << 8) + h * 16;
+        rq_int16 acc2[2];
+#pragma clang loop unroll(full)
+        for (int t = 0; t < 2; ++t)
+#pragma clang loop unroll(full)
+        for (int s = 0; s < KS; ++s) {
+            const int f = t * KS + s;
+            const rq_int4 cur = av[f % D];
+            {
+                const int r = f + D;
+                if (r < FQ) {
+                    if (r % 24 == 0) acquire(lq * SPQ + r / 24);
+                    av[f % D] = frag(r / KS, r % KS, pc);
+                } else {
+                    if (r == FQ && more) acquire(lq * SPQ + SPQ);
+                    av[f % D] = frag((r - FQ) / KS, (r - FQ) % KS, pn);
+                }
+            }
+            rq_int16 (&acc) = acc2[t];
+            if (s == 0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0;
+            }
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur, qf[s], acc, 0, 0, 0);
+            if (s == KS - 1) {
+                // block epilogue: register i is row 8 (i / 4) + 4 h + i % 4 of the 32-row block, query r32
+#pragma unroll
+                for (int bq = 0; bq < 4; ++bq) {
+                    const rq_float4 nv = *(const rq_float4*)(nrow + t * 128 + bq * 32);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        rq_insert3(m1, m2, m3, rq_pos_score_finite((float)acc[4 * bq + e] * nv[e], (uint32_t)(t * 32 + bq * 8 + e)));
+                }
+            }
+        }
+        {
+            float y1 = rq_scale_pos(m1, qsc), y2 = rq_scale_pos(m2, qsc), y3 = rq_scale_pos(m3, qsc);
+            const uint32_t hb = (uint32_t)h << 2;
+            float x1 = __uint_as_float(__float_as_uint(y1) | hb), x2 = __uint_as_float(__float_as_uint(y2) | hb), x3 = __uint_as_float(__float_as_uint(y3) | hb);
+            const float o1 = __shfl_xor(x1, 32, 64), o2 = __shfl_xor(x2, 32, 64), o3 = __shfl_xor(x3, 32, 64);
+            rq_insert3(x1, x2, x3, o1);
+            rq_insert3(x1, x2, x3, o2);
+            rq_insert3(x1, x2, x3, o3);
+            asm("v_max_f32 %0, %1, %2" : "=v"(wmax) : "v"(wmax), "v"(x1));
+            if (h == 0) stg[(32 * wave + r32) * SQ + (lq & (SQ - 1))] = rq_record_from_triple(x1, x2, x3);
+        }
+        if ((lq & (SQ - 1)) == SQ - 1 || lq == nloc - 1)
+            flush(q_lo + (lq & ~(SQ - 1)), (lq & (SQ - 1)) + 1);
+    }
+    {
+        const int ql = 32 * wave + r32;
+        if (h == 0 && ql < nq_valid) wgmax_p[(int64_t)ql * wgmax_stride + b] = wmax;
+    }
+}
+
+template <bool NT, int D>
+__global__ __launch_bounds__(512, 2) void rq_scanw32_kernel(RqScanArgs a) {
+    rq_scanw32_body<NT, D>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
 static constexpr size_t rq_scanw_lds_bytes(int QW, int QG) { return (size_t)4 * 24576 + 1024 + (size_t)16 * QW * QG * rqw_sq(QW, QG) * 8; }
 
 template <bool NT, int D, int OCC, int QW, int QG, int EPI, int DBG, int PRIO, int I8>
@@ -414,8 +577,31 @@ static hipError_t rq_scanw_launch_t(const RqScanArgs& a, int grid, hipStream_t s
 //      (A/B of the two-waves-per-SIMD levers of MI355X_MICROARCH.md: neither beats 0 once the accumulators alternate)
 //   90..95  timing experiments, results invalid: no selection / no LDS fragment reads / no MFMAs, on variant 4's (90-92)
 //      and variant 0's (93-95) shape
+template <bool NT, int D>
+static hipError_t rq_scanw32_launch_t(const RqScanArgs& a, int grid, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
+    constexpr size_t lds = rq_scanw_lds_bytes(8, 2);
+    static unsigned long long attr_done = 0;   // one bit per device
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (!((attr_done >> (dev & 63)) & 1ull)) {
+        e = hipFuncSetAttribute((const void*)rq_scanw32_kernel<NT, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done |= 1ull << (dev & 63);
+    }
+    if (e0 && e1) hipExtLaunchKernelGGL((rq_scanw32_kernel<NT, D>), dim3(grid), dim3(512), (uint32_t)lds, stream, e0, e1, 0, a);
+    else hipLaunchKernelGGL((rq_scanw32_kernel<NT, D>), dim3(grid), dim3(512), lds, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t rq_scan_wide_launch(const RqScanArgs& a, int variant, int queries, bool nt, int grid, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
     if (grid <= 0) return hipErrorInvalidValue;
+    // int8 image, 256 queries on the 32x32x32 form: 30 reads 8 fragments ahead, 31 reads 12 ahead, 32 reads 4 ahead
+    if (queries == 256 && variant >= 30 && variant <= 32) {
+        if (variant == 30) return nt ? rq_scanw32_launch_t<true, 8>(a, grid, stream, e0, e1) : rq_scanw32_launch_t<false, 8>(a, grid, stream, e0, e1);
+        if (variant == 31) return nt ? rq_scanw32_launch_t<true, 12>(a, grid, stream, e0, e1) : rq_scanw32_launch_t<false, 12>(a, grid, stream, e0, e1);
+        return nt ? rq_scanw32_launch_t<true, 4>(a, grid, stream, e0, e1) : rq_scanw32_launch_t<false, 4>(a, grid, stream, e0, e1);
+    }
 #define RQW_CASE(V, DD, OO, QQ, GG, ...) \
     if (variant == V && queries == 16 * QQ * GG) \
         return nt ? rq_scanw_launch_t<true, DD, OO, QQ, GG, ##__VA_ARGS__>(a, grid, stream, e0, e1) : rq_scanw_launch_t<false, DD, OO, QQ, GG, ##__VA_ARGS__>(a, grid, stream, e0, e1);
