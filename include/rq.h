@@ -152,7 +152,7 @@ int rq_merge_keys_device(const uint64_t* d_keys_in, int n_per_query, int B, int 
  *   whose errors add up to the repair path of rq_search_fixup_device.  When more than 1 in 16 checked queries of a class of
  *   k (<= 32 / larger) needed repair, that class moves one step along one image -> two images -> fp16 scan, until "scan8" or
  *   "scan8_split" is set again),
- * "wide256_8" (default 22: calls of more than 128 queries on the one-image class use 256-query passes over the image, a variant of
+ * "wide256_8" (default 31: calls of more than 128 queries on the one-image class use 256-query passes over the image, a variant of
  *   csrc/rq_scan_wide.hip; 0 = passes of 128 as in round 2), "bin_bound" (A/B hook, default 1: the tail tests every bin with its own rows'
  *   worst quantisation error instead of the shard's), "stripe_rows" (multi-device index, before the first append: rows per stripe),
  * "tail_local" (A/B hook, default 1: a tail workgroup with more than k re-scored rows publishes only its own k best keys),

@@ -1563,11 +1563,11 @@ def test_int8_wide_passes_match_oracle():
     q600[5] = x16[7].astype(np.float32); q600[300] = 0
     for variant in (22, 25, 30, 31, 32, 0):
         idx.set_option("wide256_8", variant)
-        for B in ((129, 257, 387, 576) if variant == 22 else (257,)):
+        for B in ((129, 257, 387, 576) if variant in (22, 31) else (257,)):
             before = int(idx.get_option("scan8_used"))
             _check(idx, x16, q600[:B], 10)
             assert int(idx.get_option("scan8_used")) == before + 1, (variant, B)
-    idx.set_option("wide256_8", 22)
+    idx.set_option("wide256_8", 31)
     _check(idx, x16, 1.5 * q600[:300], 7, nat.METRIC_IP)
     odd = nat.NativeIndex(768, 0)
     odd.add_f16(x16[:256 * 3 * 64 + 64 * 5 + 9])               # 773 quads over 256 workgroups: 3 or 4 each

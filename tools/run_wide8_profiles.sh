@@ -3,7 +3,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-SPEC="scan8=2,wide256_8=22;scan8=2,wide256_8=0"
+SPEC="scan8=2,wide256_8=31;scan8=2,wide256_8=22;scan8=2,wide256_8=0"
 rm -rf $R/gpurun_out/w8_stats $R/gpurun_out/w8_mfma $R/gpurun_out/w8_fetch $R/gpurun_out/w8_lds
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/w8_stats -- python3 $R/tools/gpu_wide_one.py 256 "$SPEC" > $R/gpurun_out/w8_stats.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/w8_mfma -- python3 $R/tools/gpu_wide_one.py 256 "$SPEC" > $R/gpurun_out/w8_mfma.log 2>&1
@@ -14,7 +14,7 @@ python - <<'PY'
 import csv, glob, json, collections
 out = {}
 ks = sorted(glob.glob("gpurun_out/w8_stats/**/*kernel_stats.csv", recursive=True))[-1]
-sel = lambda name: ("rq_scanw" in name) or ("rq_scan_kernel" in name and ", 4>" in name)
+sel = lambda name: ("rq_scanw" in name) or ("rq_scan_kernel" in name and ", 4>" in name)   # rq_scanw32_kernel (32x32x32), rq_scanw_kernel (16x16x64), rq_scan_kernel<.., 4> (128 queries)
 for r in csv.DictReader(open(ks)):
     if sel(r["Name"]):
         out.setdefault(r["Name"][:64], {})["avg_launch_us_kernel_stats"] = float(r["AverageNs"]) / 1e3
