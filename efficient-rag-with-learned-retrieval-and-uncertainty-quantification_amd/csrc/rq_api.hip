@@ -309,7 +309,7 @@ extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     else if (s == "epi" || s == "fused_epi") idx->epi = (int)v != 0;   // selection form of the 64-query scan (default variant and fused launch): 1 = positions inside the scores, 0 = compare / select
     else if (s == "profile_legacy") idx->profile_legacy = (int)v != 0;   // time scans with hipEventRecord around the launch (round 1) instead of dispatch-attached events
     else if (s == "scan8") { if (v < 0 || v > 2) return set_err(RQ_EINVAL, "scan8 must be 0, 1 or 2"); idx->scan8 = (int)v; scan8_reset_levels(idx); }   // see run_pipeline
-    else if (s == "wide256_8") { if (v != 0 && v != 22 && v != 25 && !(v >= 30 && v <= 32)) return set_err(RQ_EINVAL, "wide256_8: 0 (off) or a 256-query int8 variant of csrc/rq_scan_wide.hip (22, 25, 30..32)"); idx->wide256_8 = (int)v; }
+    else if (s == "wide256_8") { if (v != 0 && v != 22 && v != 25 && !(v >= 30 && v <= 33)) return set_err(RQ_EINVAL, "wide256_8: 0 (off) or a 256-query int8 variant of csrc/rq_scan_wide.hip (22, 25, 30..33)"); idx->wide256_8 = (int)v; }
     else if (s == "wide8") idx->wide8 = (int)v != 0;   // calls of more than 64 queries may use 128-query passes over the int8 image
     else if (s == "scan8_split") { if (v < -1 || v > 1) return set_err(RQ_EINVAL, "scan8_split must be -1, 0 or 1"); idx->scan8_split = (int)v; scan8_reset_levels(idx); }   // see run_pipeline
     else if (s == "thr_mult8") { if (!(v >= 1.05 && v <= 2.25)) return set_err(RQ_EINVAL, "thr_mult8 %g outside 1.05..2.25", v); idx->thr_mult8 = v; }

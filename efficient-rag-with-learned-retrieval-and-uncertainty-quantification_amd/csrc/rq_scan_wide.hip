@@ -386,11 +386,15 @@ __device__ __forceinline__ void rq_scanw_body(const RqScanArgs& a, const int b, 
 // ---------------------------------------------------------------------------------------------------------------------------
 typedef int rq_int16 __attribute__((ext_vector_type(16)));
 
-template <bool NT, int D>
+// QS (A/B): the DMA unit is a whole quad (48 KiB, ring of 2) instead of a 32-row block (24 KiB, ring of 4): the same LDS addresses and the
+// same bytes in flight, one workgroup barrier per quad instead of two.
+template <bool NT, int D, bool QS = false>
 __device__ __forceinline__ void rq_scanw32_body(const RqScanArgs& a, const int b, const int G) {
     static_assert(D >= 2 && D <= 12 && 48 % D == 0, "prefetch distance");
-    constexpr int QW = 8, ROWB = RQ_DPAD, KS = 24, FQ = 48, CH = ROWB / 16, STAGE_BYTES = 24576, SPQ = 2;
-    constexpr int DPW = 24 / QW, VM_KEEP = DPW, SQ = 16, NPAR = 4;
+    constexpr int QW = 8, ROWB = RQ_DPAD, KS = 24, FQ = 48, CH = ROWB / 16, STAGE_BYTES = 24576, SPQ = QS ? 1 : 2;
+    constexpr int DMA_BYTES = QS ? 2 * STAGE_BYTES : STAGE_BYTES;      // bytes of one DMA unit ("stage" of the issue / acquire logic)
+    constexpr int FPS = QS ? 48 : 24;                                  // fragments per DMA unit
+    constexpr int DPW = DMA_BYTES / 1024 / QW, VM_KEEP = DPW, SQ = 16, NPAR = 4;
     constexpr unsigned AUX = NT ? 2u : 0u;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -413,25 +417,29 @@ __device__ __forceinline__ void rq_scanw32_body(const RqScanArgs& a, const int b
     const char* gnext = xb + (int64_t)q_lo * (RQ_QUAD_ROWS * ROWB);
     const float* nsnext = a.row_scale + (int64_t)q_lo * RQ_QUAD_ROWS + lane;
     auto issue = [&](int gs) {
-        const int t = gs & 3;
-        char* l = rq_smem_w + t * STAGE_BYTES + (wave * DPW) * 1024;
+        const int t = QS ? (gs & 1) : (gs & 3);
+        char* l = rq_smem_w + t * DMA_BYTES + (wave * DPW) * 1024;
 #pragma unroll
         for (int i = 0; i < DPW; ++i)
             __builtin_amdgcn_global_load_lds((glb_ptr_w)(gnext + voff[i]), (lds_ptr_w)(l + i * 1024), 16, 0, AUX);
-        gnext += STAGE_BYTES;
+        gnext += DMA_BYTES;
         if ((gs & (SPQ - 1)) == 0) {
             if (wave == 0) __builtin_amdgcn_global_load_lds((glb_ptr_w)nsnext, (lds_ptr_w)(norm_lds + (((gs / SPQ) & (NPAR - 1)) << 8)), 4, 0, 0);
             nsnext += RQ_QUAD_ROWS;
         }
     };
     auto acquire = [&](int gs) {
-        if (gs + 1 < nst) rqw_wait_vmcnt<VM_KEEP>(); else rqw_wait_vmcnt<0>();
+        if (!QS && gs + 1 < nst) rqw_wait_vmcnt<VM_KEEP>(); else rqw_wait_vmcnt<0>();    // (QS: the next unit is only issued below, nothing younger is in flight)
+        // QS refills the slot of the unit that was read LAST (ring of 2): every wave's fragment reads of it must have returned before
+        // any wave may issue the DMA that overwrites it
+        if (QS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (gs + 2 < nst) issue(gs + 2);
+        if (QS) { if (gs + 1 < nst) issue(gs + 1); }
+        else if (gs + 2 < nst) issue(gs + 2);
     };
     issue(0);
-    if (nst > 1) issue(1);
+    if (!QS && nst > 1) issue(1);
 
     // B operand: q8[32 wave + r32][32 s + 16 h .. + 15] of k-step s
     rq_int4 qf[KS];
@@ -490,7 +498,7 @@ __device__ __forceinline__ void rq_scanw32_body(const RqScanArgs& a, const int b
             {
                 const int r = f + D;
                 if (r < FQ) {
-                    if (r % 24 == 0) acquire(lq * SPQ + r / 24);
+                    if (r % FPS == 0) acquire(lq * SPQ + r / FPS);
                     av[f % D] = frag(r / KS, r % KS, pc);
                 } else {
                     if (r == FQ && more) acquire(lq * SPQ + SPQ);
@@ -534,9 +542,9 @@ __device__ __forceinline__ void rq_scanw32_body(const RqScanArgs& a, const int b
     }
 }
 
-template <bool NT, int D>
+template <bool NT, int D, bool QS>
 __global__ __launch_bounds__(512, 2) void rq_scanw32_kernel(RqScanArgs a) {
-    rq_scanw32_body<NT, D>(a, (int)blockIdx.x, (int)gridDim.x);
+    rq_scanw32_body<NT, D, QS>(a, (int)blockIdx.x, (int)gridDim.x);
 }
 
 static constexpr size_t rq_scanw_lds_bytes(int QW, int QG) { return (size_t)4 * 24576 + 1024 + (size_t)16 * QW * QG * rqw_sq(QW, QG) * 8; }
@@ -577,7 +585,7 @@ static hipError_t rq_scanw_launch_t(const RqScanArgs& a, int grid, hipStream_t s
 //      (A/B of the two-waves-per-SIMD levers of MI355X_MICROARCH.md: neither beats 0 once the accumulators alternate)
 //   90..95  timing experiments, results invalid: no selection / no LDS fragment reads / no MFMAs, on variant 4's (90-92)
 //      and variant 0's (93-95) shape
-template <bool NT, int D>
+template <bool NT, int D, bool QS = false>
 static hipError_t rq_scanw32_launch_t(const RqScanArgs& a, int grid, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
     constexpr size_t lds = rq_scanw_lds_bytes(8, 2);
     static unsigned long long attr_done = 0;   // one bit per device
@@ -585,18 +593,19 @@ static hipError_t rq_scanw32_launch_t(const RqScanArgs& a, int grid, hipStream_t
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (!((attr_done >> (dev & 63)) & 1ull)) {
-        e = hipFuncSetAttribute((const void*)rq_scanw32_kernel<NT, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipFuncSetAttribute((const void*)rq_scanw32_kernel<NT, D, QS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done |= 1ull << (dev & 63);
     }
-    if (e0 && e1) hipExtLaunchKernelGGL((rq_scanw32_kernel<NT, D>), dim3(grid), dim3(512), (uint32_t)lds, stream, e0, e1, 0, a);
-    else hipLaunchKernelGGL((rq_scanw32_kernel<NT, D>), dim3(grid), dim3(512), lds, stream, a);
+    if (e0 && e1) hipExtLaunchKernelGGL((rq_scanw32_kernel<NT, D, QS>), dim3(grid), dim3(512), (uint32_t)lds, stream, e0, e1, 0, a);
+    else hipLaunchKernelGGL((rq_scanw32_kernel<NT, D, QS>), dim3(grid), dim3(512), lds, stream, a);
     return hipGetLastError();
 }
 
 hipError_t rq_scan_wide_launch(const RqScanArgs& a, int variant, int queries, bool nt, int grid, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
     if (grid <= 0) return hipErrorInvalidValue;
     // int8 image, 256 queries on the 32x32x32 form: 30 reads 8 fragments ahead, 31 reads 12 ahead, 32 reads 4 ahead
+    if (queries == 256 && variant == 33) return nt ? rq_scanw32_launch_t<true, 12, true>(a, grid, stream, e0, e1) : rq_scanw32_launch_t<false, 12, true>(a, grid, stream, e0, e1);   // 31 with whole-quad DMA units
     if (queries == 256 && variant >= 30 && variant <= 32) {
         if (variant == 30) return nt ? rq_scanw32_launch_t<true, 8>(a, grid, stream, e0, e1) : rq_scanw32_launch_t<false, 8>(a, grid, stream, e0, e1);
         if (variant == 31) return nt ? rq_scanw32_launch_t<true, 12>(a, grid, stream, e0, e1) : rq_scanw32_launch_t<false, 12>(a, grid, stream, e0, e1);

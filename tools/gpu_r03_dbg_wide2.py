@@ -17,7 +17,7 @@ def pooled(variant):
 ref = pooled(0)            # two 128-query passes (rq_scan.hip I8 = 3)
 print("grid quads per wg:", nb / 256)
 for rep in range(12):
-    for v in (22, 25, 30, 31, 32):
+    for v in (22, 25, 30, 31, 32, 33):
         got = pooled(v)
         bad = np.argwhere(got != ref)
         if len(bad):

@@ -16,8 +16,8 @@ for B in (256, 512, 500, 192):
     q = torch.randn((B, 768), device=dev, generator=gq)
     sc = torch.empty((B, k), device=dev); rw = torch.empty((B, k), device=dev, dtype=torch.int64); st = torch.zeros((B,), device=dev, dtype=torch.int32)
     rows = {}
-    for name, w8, v in (("int8 256-pass v22", 1, 22), ("int8 256-pass v25", 1, 25), ("int8 256 32x32 v30", 1, 30), ("int8 256 32x32 v31", 1, 31), ("int8 256 32x32 v32", 1, 32), ("int8 128-passes   ", 1, 0), ("fp16 wide passes  ", 0, 22),
-                        ("int8 256-pass v22", 1, 22), ("int8 256 32x32 v30", 1, 30), ("int8 128-passes   ", 1, 0)):
+    for name, w8, v in (("int8 256-pass v22", 1, 22), ("int8 256-pass v25", 1, 25), ("int8 256 32x32 v30", 1, 30), ("int8 256 32x32 v31", 1, 31), ("int8 256 32x32 v33", 1, 33), ("int8 256 32x32 v32", 1, 32), ("int8 128-passes   ", 1, 0), ("fp16 wide passes  ", 0, 22),
+                        ("int8 256 32x32 v31", 1, 31), ("int8 256 32x32 v33", 1, 33), ("int8 128-passes   ", 1, 0)):
         idx.set_option("wide8", w8); idx.set_option("wide256_8", v); idx.set_option("profile", 0)
         for _ in range(5): idx.search_device(q, B, k, 0, sc, rw, None, st, 0)
         torch.cuda.synchronize(); idx.reset_timing(); idx.set_option("profile", 1); idx.set_option("profile_stride", 1)
