@@ -862,7 +862,7 @@ def test_long_structured_sweep():
         idx.set_option("scan8", int(rng.choice([0, 1, 2, 2, 2])))        # the int8 image: never / size rule / always,
         idx.set_option("scan8_split", int(rng.choice([-1, -1, 0, 1])))    #   one or two images per query, 128-query passes
         idx.set_option("wide8", int(rng.choice([1, 1, 0])))
-        idx.set_option("wide256_8", int(rng.choice([22, 30, 31, 32, 25, 0])))     # round 3: 256-query int8 passes (two read-ahead distances) / passes of 128
+        idx.set_option("wide256_8", int(rng.choice([22, 30, 31, 32, 33, 25, 0])))     # round 3: 256-query int8 passes (two read-ahead distances) / passes of 128
         idx.set_option("bin_bound", int(rng.choice([1, 1, 0])))           #   per-bin quantisation bound in the tail
         idx.set_option("exact_mfma", int(rng.choice([1, 1, 0])))          #   exact scan on the fp64 matrix cores (repairs that reach the last rung)
         try:
@@ -1561,7 +1561,7 @@ def test_int8_wide_passes_match_oracle():
     # whose workgroups own an ODD number of quads (ring parity), and 0 = off (passes of 128 as in round 2)
     q600 = orc.synthetic_queries(600, 768, seed=17)
     q600[5] = x16[7].astype(np.float32); q600[300] = 0
-    for variant in (22, 25, 30, 31, 32, 0):
+    for variant in (22, 25, 30, 31, 32, 33, 0):
         idx.set_option("wide256_8", variant)
         for B in ((129, 257, 387, 576) if variant in (22, 31) else (257,)):
             before = int(idx.get_option("scan8_used"))
