@@ -449,3 +449,32 @@ def test_batched_fusion_in_row_space_equals_the_per_query_path(tmp_path, metric)
     # the key space follows the stores: a document added later is found by the batch path too
     r.bm25_index.add_documents([docs[100]])
     assert r.get_scores_for_router_batch([texts[100]], 5) == [r.get_scores_for_router(texts[100], 5)]
+
+
+def test_committed_bench_line_has_the_contract_shape():
+    """profiles/r03_bench20.json is a `python bench.py --steps 20 --warmup 5` line from the GPU box (tools/run_profiles.sh): the keys the
+    driver and the review read, on BASELINE's basis -- fp16 rows as `value`, 1536 B per row in the roofline, the int8 image and the
+    structured corpora as sibling objects -- and the internal consistency of the numbers (kernel <= step, achieved = bytes / time)."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_bench20.json")
+    d = json.loads(open(path).read())
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline", "int8_scan", "structured", "host_api", "ids_exact", "recall_at_10", "timed_path_vs_exact_fp64_scan"):
+        assert key in d, key
+    assert d["dtype"] == "f16" and d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["vs_baseline"] is None and d["scaling"] == "strong"
+    assert "workload" in d["config"] and "1536 B per row" in d["config"]["workload"] and d["config"]["ranks_seen"] == 1 and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and r["algorithmic_bytes_per_launch"] == 1_000_000 * 1536
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 1e-6 * r["achieved"] and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
+    assert r["avg_launch_us"] <= d["ms_per_step"] * 1e3 * 1.001                     # the kernel fits in the step
+    assert abs(d["value"] - 64 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert 0.6 <= r["frac"] <= 1.0 and r["traffic"] is not None and 1.0 <= r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.1
+    assert d["ids_exact"] and d["recall_at_10"] == 1.0 and d["timed_path_vs_exact_fp64_scan"]["ids_match"]
+    i8 = d["int8_scan"]
+    assert i8["dtype"] == "i8" and i8["extra_hbm_bytes_per_row"] == 768 and i8["roofline"]["algorithmic_bytes_per_launch"] == 1_000_000 * 768 and i8["ids_exact"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and d["value"] >= 10 * c["value"]            # north star: >= 10x the CPU path
+    for corpus in ("documents/random", "documents/on-topic", "centroids/random", "centroids/on-topic"):
+        for operand in ("fp16", "int8", "auto"):
+            assert d["structured"][corpus][operand]["ids_match_exact_fp64_scan"], (corpus, operand)
+    assert "python_seam" in d["host_api"] and "batch_1_k50" in d["host_api"]["python_seam"]
