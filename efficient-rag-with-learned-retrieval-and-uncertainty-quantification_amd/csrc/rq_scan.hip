@@ -422,7 +422,8 @@ static hipError_t rq_scan_tail_launch_e(const RqScanArgs& sa, const RqTailArgs& 
     // scan a little while it is resident (measured at 1M rows: 256 workgroups of 4096 bins 248.7 us per launch, 512 of
     // 2048 bins 252.4 us).  The stand-alone launch (rq_tail_launch) prefers more, smaller ones: lower latency.
     const auto wgs = [&](int nv) { return ((ta.nbins + 512 * nv - 1) / (512 * nv)) * tail_B; };
-    const int nv = (ta.fused_nv == 1 || ta.fused_nv == 4 || ta.fused_nv == 8) ? ta.fused_nv : (wgs(1) <= 384 ? 1 : (wgs(4) <= 384 ? 4 : 8));
+    const int nv = (ta.fused_nv == 1 || ta.fused_nv == 4 || ta.fused_nv == 8 || ta.fused_nv == 16) ? ta.fused_nv : (wgs(1) <= 384 ? 1 : (wgs(4) <= 384 ? 4 : 8));
+    if (nt && nv == 16) return rq_scan_tail_launch_t<true, 16, EPI>(sa, ta, tail_B, pa, scan_grid, stream, e0, e1);   // development (fused_nv = 16): 128 riding workgroups at 1M rows
     if (nt) return nv == 1 ? rq_scan_tail_launch_t<true, 1, EPI>(sa, ta, tail_B, pa, scan_grid, stream, e0, e1)
                  : nv == 4 ? rq_scan_tail_launch_t<true, 4, EPI>(sa, ta, tail_B, pa, scan_grid, stream, e0, e1)
                            : rq_scan_tail_launch_t<true, 8, EPI>(sa, ta, tail_B, pa, scan_grid, stream, e0, e1);
