@@ -960,7 +960,7 @@ class HybridRetriever:
         fusion per query."""
         fused = self._fuse_batch_rows(queries, top_k, retrieval_pool_size)
         if fused is not None:
-            ids, _, b, de, hy, count = fused
+            ids, b, de, hy, count = fused
             idl, bl, dl, hl = ids.tolist(), b.tolist(), de.tolist(), hy.tolist()
             out = []
             for q in range(len(queries)):
@@ -1010,11 +1010,12 @@ class HybridRetriever:
         fused columns (no RetrievalResult objects in between)."""
         fused = self._fuse_batch_rows(queries, num_passages, retrieval_pool_size)
         if fused is not None:
-            ids, texts, b, de, _, count = fused
-            pad_mask = np.arange(num_passages)[None, :] >= count[:, None]
-            ids[pad_mask] = ""
-            texts[pad_mask] = ""
-            return list(zip(b.tolist(), de.tolist(), ids.tolist(), texts.tolist()))
+            ids, b, de, _, count = fused
+            ids[np.arange(num_passages)[None, :] >= count[:, None]] = ""
+            idl = ids.tolist()
+            documents = self.documents                      # (texts are read from the store at call time, as the per-query path does)
+            texts = [[documents[d].text if d else "" for d in row] for row in idl]
+            return list(zip(b.tolist(), de.tolist(), idl, texts))
         dense, sparse = self._pools_batch(queries, retrieval_pool_size)
         documents = self.documents
         out = []
@@ -1030,8 +1031,8 @@ class HybridRetriever:
     # ---- batched fusion in row space (extension; configs[4]: 500 questions x two pools of 100) ------------------------------------
     def _key_space(self):
         """One integer key per document either index can return: BM25 row r -> r, dense row j -> the BM25 row of the same id if BM25
-        holds it, else n_bm25 + j.  Per key: the id, the text `self.documents` holds for it, and whether `self.documents` knows it at all
-        (reference :491-493 skips ids it does not).  Rebuilt when any of the three stores has grown."""
+        holds it, else n_bm25 + j.  Per key: the id and whether `self.documents` knows it at all (reference :491-493 skips ids it does
+        not).  Rebuilt when any of the three stores has grown."""
         bm, dn = self.bm25_index, self.dense_index
         stamp = (len(bm.doc_ids), len(dn._ids), len(self.documents))
         c = self.__dict__.get("_keys_cache")
@@ -1045,15 +1046,13 @@ class HybridRetriever:
         ids[:] = all_ids
         docs = self.documents
         known = np.fromiter((d in docs for d in all_ids), np.bool_, len(all_ids))
-        texts = np.empty(len(all_ids), dtype=object)
-        texts[:] = [docs[d].text if d in docs else "" for d in all_ids]
-        c = self.__dict__["_keys_cache"] = {"stamp": stamp, "nb": nb, "dense_key": dense_key, "ids": ids, "texts": texts, "known": known}
+        c = self.__dict__["_keys_cache"] = {"stamp": stamp, "nb": nb, "dense_key": dense_key, "ids": ids, "known": known}
         return c
 
     def _fuse_batch_rows(self, queries: Sequence[str], top_k: int, retrieval_pool_size: int):
         """`_fuse_columns` for every query of the batch at once, on integer keys: same candidates (union of both pools in first-seen
         order -- BM25 pool, then dense pool -- ids unknown to `self.documents` dropped), same float64 arithmetic (`max(...) or 1` over all
-        candidates, hybrid = (b/max_b + d/max_d)/2), same stable descending sort, first top_k.  Returns (ids [B][top_k] object, texts,
+        candidates, hybrid = (b/max_b + d/max_d)/2), same stable descending sort, first top_k.  Returns (ids [B][top_k] object,
         bm25 scores, dense scores, hybrid scores, count [B]) -- entries beyond count[b] are padding -- or None when one of the two sides
         is not this module's own index class (then the per-query path runs)."""
         bm, dn = self.bm25_index, self.dense_index
@@ -1094,7 +1093,7 @@ class HybridRetriever:
         b = np.where(live, np.take_along_axis(bsc, sel, 1), 0.0)
         de = np.where(live, np.take_along_axis(dsc, sel, 1), 0.0)
         hy = np.where(live, np.take_along_axis(h, sel, 1), 0.0)
-        return ks["ids"][out_keys], ks["texts"][out_keys], b, de, hy, count
+        return ks["ids"][out_keys], b, de, hy, count
 
     def close(self) -> None:
         """Write the BM25 snapshot if documents were added since the last one (extension; the reference has no close)."""

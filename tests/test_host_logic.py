@@ -446,6 +446,10 @@ def test_batched_fusion_in_row_space_equals_the_per_query_path(tmp_path, metric)
         assert r.hybrid_search_batch(queries, top_k=num, retrieval_pool_size=pool) == [r.hybrid_search(q, top_k=num, retrieval_pool_size=pool) for q in queries]
     flat = [i for q in queries for i in r.get_scores_for_router(q, 100, retrieval_pool_size=100)[2]]
     assert any(i.startswith("donly") for i in flat) and not any(i.startswith("ghost") for i in flat)
+    # texts come from the store at call time: a document whose text was replaced answers with the new text on both paths
+    r.documents["p5"] = si.Document(id="p5", text="replaced text", title="T5")
+    assert r.get_scores_for_router_batch([texts[5]], 5, retrieval_pool_size=50) == [r.get_scores_for_router(texts[5], 5, retrieval_pool_size=50)]
+    assert "replaced text" in r.get_scores_for_router_batch([texts[5]], 50, retrieval_pool_size=50)[0][3]
     # the key space follows the stores: a document added later is found by the batch path too
     r.bm25_index.add_documents([docs[100]])
     assert r.get_scores_for_router_batch([texts[100]], 5) == [r.get_scores_for_router(texts[100], 5)]
