@@ -223,10 +223,14 @@ __device__ __forceinline__ void rq_scan_body(const RqScanArgs& a, const int b, c
             const int64_t row0 = (int64_t)quad * RQ_QUAD_ROWS + t * RQ_TILE_ROWS + 4 * kg;
             if (EPI == 1) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) rq_insert3(m1, m2, m3, rq_pos_score(acc[i] * nv[i], (uint32_t)(t * 16 + i)));
+                for (int i = 0; i < 4; ++i) {
+                    // (int8: the score is an exact int32 sum times a finite row scale, or NaN on pad rows -- no clamp needed, rq_device.h)
+                    if constexpr (I8 != 0) rq_insert3(m1, m2, m3, rq_pos_score_finite(acc[i] * nv[i], (uint32_t)(t * 16 + i)));
+                    else rq_insert3(m1, m2, m3, rq_pos_score(acc[i] * nv[i], (uint32_t)(t * 16 + i)));
+                }
                 if constexpr (I8 == 3) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) rq_insert3(n1, n2, n3, rq_pos_score((float)lacc[i] * nv[i], (uint32_t)(t * 16 + i)));
+                    for (int i = 0; i < 4; ++i) rq_insert3(n1, n2, n3, rq_pos_score_finite((float)lacc[i] * nv[i], (uint32_t)(t * 16 + i)));
                 }
             } else
 #pragma unroll
