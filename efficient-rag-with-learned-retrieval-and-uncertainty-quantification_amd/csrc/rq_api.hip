@@ -796,9 +796,12 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
         pa.q8 = cx.ring_q8[nslot]; pa.qscale8 = cx.ring_qscale8[nslot]; pa.qeps8 = cx.ring_qeps8[nslot];
         pa.q8lo = cx.ring_q8lo[nslot]; pa.qeps8s = cx.ring_qeps8s[nslot];
     }
-    // one scan grid for every pass of the call (the tail reads nwg partition maxima per query): the widest pass decides
-    // every fp16 pass of more than 64 queries, and the int8 256-query pass, runs one 512-thread workgroup per CU
-    int wg_cu = (qb0 > 64 && (!use8 || qb0 == 256 || idx->wide128_8)) ? 1 : idx->wg_per_cu;
+    // Scan grids.  Every fp16 pass of more than 64 queries, and the int8 256-query pass, runs ONE 512-thread workgroup per CU ("wide");
+    // the 64-query passes and the int8 128-query pass run wg_per_cu 256-thread workgroups per CU.  A call's passes are cut widest first,
+    // so its wide passes precede its narrow ones: the tail is told where the second grid starts (nwg_split).  Until round 3 the first
+    // pass's grid served the whole call, and the remainder pass of e.g. 384 int8 queries ran at half its occupancy (232 us instead of 150).
+    auto pass_wide = [&](int qb) { return qb > 64 && (!use8 || qb == 256 || idx->wide128_8); };
+    int wg_cu = idx->wg_per_cu;
     // Small int8 shards searched from SEVERAL caller streams (the per-rank shape of a multi-GPU run: 125k rows, two streams): two fused
     // launches are resident at once, so ONE scan workgroup per CU and launch already keeps two per CU streaming, and each lives twice as
     // long -- the prologue (48 KB of query fragments + the ring fill) is paid half as often.  Measured, two streams + exchange, us per
@@ -809,13 +812,17 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
         for (auto& kv : idx->ctx) other_stream_busy = other_stream_busy || (kv.first != s && kv.second.fused_pending);
         if (other_stream_busy) wg_cu = 1;
     }
-    const int grid = (int)std::min<int64_t>(std::min<int64_t>(nquads, RQ_WGMAX_STRIDE), (int64_t)idx->cu_count * wg_cu);
+    const int grid_narrow = (int)std::min<int64_t>(std::min<int64_t>(nquads, RQ_WGMAX_STRIDE), (int64_t)idx->cu_count * wg_cu);
+    const int grid_wide = (int)std::min<int64_t>(std::min<int64_t>(nquads, RQ_WGMAX_STRIDE), (int64_t)idx->cu_count);
+    int nwg_split = bpad;                                          // first query of the first narrow pass
+    for (int blk = npass - 1, q0 = bpad; blk >= 0 && !pass_wide(pass_q[blk]); --blk) nwg_split = (q0 -= pass_q[blk]);
     if (!exact) {
         // non-temporal loads only for shards that cannot stay in the 256 MiB Infinity Cache between two scans
         // (measured: 192 MB shard 36 us with default policy vs 39 us nt; 1.5 GB shard 250 us nt vs 285 us default)
         const bool nt = idx->nt < 0 ? (idx->n * (int64_t)(use8 ? RQ_DPAD : RQ_DPAD * 2) > ((int64_t)208 << 20)) : idx->nt != 0;
         for (int blk = 0, q0 = 0; blk < npass; q0 += pass_q[blk], ++blk) {
             const int qb = pass_q[blk];
+            const int grid = q0 >= nwg_split ? grid_narrow : grid_wide;
             RqScanArgs a;
             a.i8 = 0; a.qscale = nullptr; a.qlo = nullptr;
             a.x = idx->x;
@@ -881,7 +888,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
             RqTailArgs ta;
             ta.q = d_q; ta.dim = idx->dim; ta.x = idx->x; ta.rownorm64 = idx->rownorm64; ta.n_rows = idx->n;
             ta.bins = w.bins; ta.bins_stride = w.bins_stride; ta.nbins = nbins;
-            ta.wgmax = w.wgmax; ta.wgmax_stride = RQ_WGMAX_STRIDE; ta.nwg = grid;
+            ta.wgmax = w.wgmax; ta.wgmax_stride = RQ_WGMAX_STRIDE; ta.nwg = grid_wide; ta.nwg_split = nwg_split; ta.nwg2 = grid_narrow;
             ta.m = (int)std::min<int64_t>(k, idx->n); ta.metric = metric; ta.k = k;
             ta.eps = use8 ? scan8_eps(idx) : scan_eps(idx, metric);
             ta.qeps = use8 ? (split8 ? qeps8s : qeps8) : nullptr;

@@ -121,6 +121,7 @@ struct RqTailArgs {
     const void* x; const double* rownorm64; int64_t n_rows;
     const uint2* bins; int64_t bins_stride; int64_t nbins;
     const float* wgmax; int wgmax_stride; int nwg;
+    int nwg_split, nwg2;                           // queries >= nwg_split were scanned by a grid of nwg2 workgroups (a call's narrow passes follow its wide ones)
     int m, metric, k;
     float eps, max_row_norm;
     int64_t row_offset;

@@ -68,6 +68,7 @@ __device__ __forceinline__ void rq_tail_body(const RqTailArgs& a, const int chun
     //      64 partitions (one per lane) for m <= 8, 256 for m <= 64, else 512: more partitions = tighter P.
     if (wave == 0) {
         const float* w = a.wgmax + (int64_t)q * a.wgmax_stride;
+        const int nwg = q >= a.nwg_split ? a.nwg2 : a.nwg;
         uint32_t prefix = 0;
         auto select = [&](auto npl_tag) {
             constexpr int NPL = decltype(npl_tag)::value;   // partitions per lane
@@ -75,7 +76,7 @@ __device__ __forceinline__ void rq_tail_body(const RqTailArgs& a, const int chun
 #pragma unroll
             for (int i = 0; i < NPL; ++i) {
                 float v = NEG_INF;
-                for (int j = i * 64 + lane; j < a.nwg; j += 64 * NPL) v = fmaxf(v, w[j]);
+                for (int j = i * 64 + lane; j < nwg; j += 64 * NPL) v = fmaxf(v, w[j]);
                 key[i] = rq_mono32(v);
             }
             for (int bit = 31; bit >= 12; --bit) {

@@ -26,4 +26,17 @@ for B in (128, 100, 384):
         t = idx.timing(); rows[v] = rw.cpu().numpy().copy()
         print(f"B={B:4d} wide128_8={v:2d}: {dt * 1e6:7.1f} us per call  {B / dt:9.0f} q/s  scan launches {t['scan_launches'] // 30} avg {t['scan_ms'] / max(t['scan_launches'], 1) * 1e3:6.1f} us  uncertified {int(st.sum())}", flush=True)
     print(f"B={B}: same rows: {np.array_equal(rows[0], rows[26])}", flush=True)
+# remainder passes of fp16 calls (128 + 64, 256 + 64): the 64-query pass now runs on its own two-per-CU grid
+idx.set_option("scan8", 0); idx.set_option("wide128_8", 0)
+for B in (192, 320, 448):
+    q = torch.randn((B, 768), device=dev)
+    sc = torch.empty((B, k), device=dev); rw = torch.empty((B, k), device=dev, dtype=torch.int64); st = torch.zeros((B,), device=dev, dtype=torch.int32)
+    idx.set_option("profile", 0)
+    for _ in range(5): idx.search_device(q, B, k, 0, sc, rw, None, st, 0)
+    torch.cuda.synchronize(); idx.reset_timing(); idx.set_option("profile", 1); idx.set_option("profile_stride", 1)
+    t0 = time.perf_counter()
+    for _ in range(30): idx.search_device(q, B, k, 0, sc, rw, None, st, 0)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 30
+    t = idx.timing()
+    print(f"fp16 B={B:4d}: {dt * 1e6:7.1f} us per call  {B / dt:9.0f} q/s  scan launches {t['scan_launches'] // 30} avg {t['scan_ms'] / max(t['scan_launches'], 1) * 1e3:6.1f} us  uncertified {int(st.sum())}", flush=True)
 idx.close()
