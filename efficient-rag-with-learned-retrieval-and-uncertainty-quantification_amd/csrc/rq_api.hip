@@ -310,7 +310,6 @@ extern "C" int rq_set_option(rq_index* idx, const char* name, double v) {
     else if (s == "profile_legacy") idx->profile_legacy = (int)v != 0;   // time scans with hipEventRecord around the launch (round 1) instead of dispatch-attached events
     else if (s == "scan8") { if (v < 0 || v > 2) return set_err(RQ_EINVAL, "scan8 must be 0, 1 or 2"); idx->scan8 = (int)v; scan8_reset_levels(idx); }   // see run_pipeline
     else if (s == "wide256_8") { if (v != 0 && v != 22 && v != 25 && !(v >= 30 && v <= 33)) return set_err(RQ_EINVAL, "wide256_8: 0 (off) or a 256-query int8 variant of csrc/rq_scan_wide.hip (22, 25, 30..33)"); idx->wide256_8 = (int)v; }
-    else if (s == "wide128_8") { if (v != 0 && v != 26) return set_err(RQ_EINVAL, "wide128_8: 0 (rq_scan.hip's 128-query int8 pass) or 26 (the rq_scan_wide.hip form)"); idx->wide128_8 = (int)v; }
     else if (s == "wide8") idx->wide8 = (int)v != 0;   // calls of more than 64 queries may use 128-query passes over the int8 image
     else if (s == "scan8_split") { if (v < -1 || v > 1) return set_err(RQ_EINVAL, "scan8_split must be -1, 0 or 1"); idx->scan8_split = (int)v; scan8_reset_levels(idx); }   // see run_pipeline
     else if (s == "thr_mult8") { if (!(v >= 1.05 && v <= 2.25)) return set_err(RQ_EINVAL, "thr_mult8 %g outside 1.05..2.25", v); idx->thr_mult8 = v; }
@@ -722,7 +721,6 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     const bool piped = fast && may_defer && idx->pipeline == 1;
     // fused mode: one scan launch per call (<= 64 queries), which carries the tail of the previous call
     const bool fused = fast && may_defer && idx->pipeline == 2 && bpad == 64;
-    const int qb0 = pass_q[0];
     int par = 0, slot = -1;
     if (fused) {
         slot = (int)(cx.calls % 3);
@@ -800,7 +798,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     // the 64-query passes and the int8 128-query pass run wg_per_cu 256-thread workgroups per CU.  A call's passes are cut widest first,
     // so its wide passes precede its narrow ones: the tail is told where the second grid starts (nwg_split).  Until round 3 the first
     // pass's grid served the whole call, and the remainder pass of e.g. 384 int8 queries ran at half its occupancy (232 us instead of 150).
-    auto pass_wide = [&](int qb) { return qb > 64 && (!use8 || qb == 256 || idx->wide128_8); };
+    auto pass_wide = [&](int qb) { return qb > 64 && (!use8 || qb == 256); };
     int wg_cu = idx->wg_per_cu;
     // Small int8 shards searched from SEVERAL caller streams (the per-rank shape of a multi-GPU run: 125k rows, two streams): two fused
     // launches are resident at once, so ONE scan workgroup per CU and launch already keeps two per CU streaming, and each lives twice as
@@ -866,7 +864,6 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
                 HIPCHK(rq_scan_tail_launch(a, none, 0, pa, nt, grid, idx->epi, s, e0, e1));
             } else if (fused) HIPCHK(rq_scan_launch(a, 3, 1, 2, 4, nt, grid, idx->epi, s, e0, e1));
             else if (use8 && qb == 256) HIPCHK(rq_scan_wide_launch(a, idx->wide256_8, 256, nt, grid, s, e0, e1));   // 256 queries over the int8 image
-            else if (use8 && qb == 128 && idx->wide128_8) HIPCHK(rq_scan_wide_launch(a, idx->wide128_8, 128, nt, grid, s, e0, e1));   // A/B: 128 queries, rq_scan_wide.hip form
             else if (use8) HIPCHK(rq_scan_launch(a, 3, 1, 2, 4, nt, grid, 1, s, e0, e1));   // 64 queries, or 128 (a.i8 = 3)
             else if (qb == 256) HIPCHK(rq_scan_wide_launch(a, idx->wide256, 256, nt, grid, s, e0, e1));
             else if (qb == 128 && idx->wide_batch == 2) HIPCHK(rq_scan_launch(a, 3, 4, 1, 8, nt, grid, 0, s, e0, e1));   // round 1's 8-wave pass

@@ -131,7 +131,7 @@ struct rq_index {
     int64_t hints_used = 0;        // rq_search_hint_next_device: searches that skipped their preparation launch
     uint64_t scan_seq = 0;         // scan launches seen while profile = 1 (every profile_stride-th one is timed)
     // options
-    int ring = 3, prefetch = 1, kstage = 2, wide_batch = 1, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, profile_stride = 1, scan_nostore = 0, fast_tail = 1, pipeline = 0, tail_stop = 0, poison_cand = 0, wide128 = 0, wide256 = 2, epi = 1, use_hint = 1, profile_legacy = 0, scan8 = 1, tail_local = 1, scan8_split = -1, wide8 = 1, wide256_8 = 31, wide128_8 = 0, bin_bound = 1, exact_mfma = 1, fused_nv = 0;
+    int ring = 3, prefetch = 1, kstage = 2, wide_batch = 1, wg_per_cu = 2, nt = -1, slack_bins = -1, profile = 0, profile_stride = 1, scan_nostore = 0, fast_tail = 1, pipeline = 0, tail_stop = 0, poison_cand = 0, wide128 = 0, wide256 = 2, epi = 1, use_hint = 1, profile_legacy = 0, scan8 = 1, tail_local = 1, scan8_split = -1, wide8 = 1, wide256_8 = 31, bin_bound = 1, exact_mfma = 1, fused_nv = 0;
     double thr_mult8 = 1.25;       // int8 scan: threshold = P - thr_mult8 * bound (rq_tail_body.h)
     double eps = -1.0;
     std::map<hipStream_t, StreamCtx> ctx;

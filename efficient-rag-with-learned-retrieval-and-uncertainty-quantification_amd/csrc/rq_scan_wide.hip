@@ -624,8 +624,8 @@ hipError_t rq_scan_wide_launch(const RqScanArgs& a, int variant, int queries, bo
     //     differently from run to run.  An asm ds_read is invisible to the compiler's own hazard tracking: it may copy or re-use the
     //     destination register before the data has landed.  Removed; and the fp16 256-query default went back from 11 to 2 for the same reason.)
     RQW_CASE(22, 12, 2, 8, 2, 1, 0, 0, 1) RQW_CASE(25, 6, 2, 8, 2, 1, 0, 0, 1)
-    // 26  128 queries over the int8 image: 8 waves x 1 group of 16, one workgroup per CU (A/B against rq_scan.hip's I8 = 3 form: 4 waves x 2 groups, two per CU)
-    RQW_CASE(26, 12, 2, 8, 1, 1, 0, 0, 1)
+    // (a 128-query int8 form here -- 8 waves x 1 group, one workgroup per CU -- measured 154-160 us per pass against 150-157 of rq_scan.hip's
+    //  I8 = 3 form, 4 waves x 2 groups at two per CU: not kept)
     RQW_CASE(90, 4, 2, 8, 1, 0, 1) RQW_CASE(91, 4, 2, 8, 1, 0, 2) RQW_CASE(92, 4, 2, 8, 1, 0, 3)
     RQW_CASE(93, 12, 2, 8, 1, 1, 1) RQW_CASE(94, 12, 2, 8, 1, 1, 2) RQW_CASE(95, 12, 2, 8, 1, 1, 3)
 #undef RQW_CASE

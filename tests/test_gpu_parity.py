@@ -1563,7 +1563,7 @@ def test_int8_wide_passes_match_oracle():
     q600[5] = x16[7].astype(np.float32); q600[300] = 0
     for variant in (22, 25, 30, 31, 32, 33, 0):
         idx.set_option("wide256_8", variant)
-        for B in ((129, 257, 387, 576) if variant in (22, 31) else (257,)):
+        for B in ((129, 257, 380, 387, 576) if variant in (22, 31) else (257,)):   # 380 = 256 + 128, 576 = 2 x 256 + 64: two scan grids in one call
             before = int(idx.get_option("scan8_used"))
             _check(idx, x16, q600[:B], 10)
             assert int(idx.get_option("scan8_used")) == before + 1, (variant, B)
@@ -1583,6 +1583,8 @@ def test_int8_wide_passes_match_oracle():
     _check(idx, x16, orc.synthetic_queries(130, 768, seed=4), 100)  # k > 32: two-image class -> the fp16 wide passes
     idx.set_option("wide8", 0)
     _check(idx, x16, orc.synthetic_queries(130, 768, seed=5), 10)   # switched off -> the fp16 wide passes
+    _check(idx, x16, q600[:448], 10)                                  # fp16 256 + 128 + 64: the 64-query remainder on its own (two-per-CU) grid
+    _check(idx, x16, q600[:300], 100)                                 # fp16 256 + 64, k = 100
     assert int(idx.get_option("scan8_used")) == before
     assert idx.timing()["exact_scans"] <= 2                          # (the zero queries may take the exact route)
     idx.close()
