@@ -18,6 +18,7 @@ batch) at every N -- `--scan fp16` is the default and the operand is named in co
   "int8_scan"     N = 1: the same loop with the library's int8 image of the shard as the scan operand (768 B per row read, +768 B
                   per row of HBM; every returned row is still re-scored in fp64 from the fp16 rows and certified): its own value,
                   roofline, traffic and oracle check
+  "k100"          N = 1: the same loop at k = 100 (SURVEY 8(d) quotes configs[1] at k = 10 and k = 100), both operands
   "structured"    N = 1: both operands on document-structured and clustered 1M-row corpora (the int8 scan's data dependence)
   "host_api"      N = 1: the blocking host-buffer calls (rq_search, DenseIndex.search_vectors) beside `value`
 `--scan int8` / `--scan auto` make the int8 image / the library's own rule the main figure instead (dtype then says "i8").
@@ -153,8 +154,8 @@ def main() -> None:
     class Loop:
         """The timed loop over one index: per-batch output slots that stay in HBM, the enqueue / flush / finish / repair steps."""
 
-        def __init__(self, idx, qs):
-            self.idx, self.qs = idx, qs
+        def __init__(self, idx, qs, k=k):
+            self.idx, self.qs, self.k = idx, qs, k
             self.status_all = torch.zeros((N_QUERY_BATCHES, B), device=dev, dtype=torch.int32)   # one read-back checks every slot
             self.slots = [dict(scores=torch.empty((B, k), device=dev), rows=torch.empty((B, k), device=dev, dtype=torch.int64),
                                keys=torch.empty((B, k), device=dev, dtype=torch.int64), status=self.status_all[j]) for j in range(N_QUERY_BATCHES)]
@@ -176,6 +177,7 @@ def main() -> None:
 
         def flush(self):
             """all-gather the local keys of the pending batches (one RCCL call) and merge them on the GPU"""
+            k = self.k
             idx, pending = self.idx, self.pending
             for s in streams:
                 idx.search_flush_device(s.cuda_stream)      # deferred tails of earlier searches run / become ordered on s
@@ -198,6 +200,7 @@ def main() -> None:
                     s.wait_event(ev)
 
         def step(self, i: int) -> None:
+            k = self.k
             idx, pending = self.idx, self.pending
             j = i % N_QUERY_BATCHES
             s = streams[i % len(streams)]
@@ -212,6 +215,7 @@ def main() -> None:
                     self.flush()
 
         def run_steps(self, n: int) -> None:
+            k = self.k
             i = 0
             while i < n:
                 if self.trains is not None and self.pending["n"] == 0 and i % N_QUERY_BATCHES == 0 and n - i >= GATHER_EVERY:
@@ -237,6 +241,7 @@ def main() -> None:
 
         def fixup_all(self, nsteps: int) -> int:
             """certificate check of every slot (inside the timed region): repairs uncertified queries exactly"""
+            k = self.k
             idx, fixed = self.idx, 0
             nslots = min(N_QUERY_BATCHES, nsteps)
             bad = self.status_np[:nslots].any(axis=1)                          # (finish() has copied and synchronised)
@@ -256,6 +261,7 @@ def main() -> None:
             return fixed
 
         def preheat(self):
+            k = self.k
             # Set-up, not warm-up steps: a process that has only generated its corpus so far runs its first ~100 launches
             # 10-15 % slower (measured: scan launch 278 us in a 64-step run after 8 warm-up steps, 244 us in a 400-step run).
             # Keep the GPU busy with the same launches for 0.1 s first, so that short --steps/--warmup runs measure the same
@@ -324,6 +330,7 @@ def main() -> None:
 
         def calibrate(self) -> dict:
             """outside the timed region: the plain scan kernel (pipeline 0, tail after it) on ONE stream, an event pair on every launch"""
+            k = self.k
             idx = self.idx
             idx.set_option("pipeline", 0)
             idx.set_option("profile", 1)
@@ -342,6 +349,7 @@ def main() -> None:
         def exact_fp64_check(self, r: dict, nslots: int) -> dict:
             """slots of the timed path against the library's own exact route (every row of the shard re-scored in fp64, no approximate
             scan, no certificate: option slack_bins >= number of bins) -- no oracle involved"""
+            k = self.k
             idx = self.idx
             idx.set_option("pipeline", 0)
             idx.set_option("slack_bins", max(len(idx), 64))
@@ -474,6 +482,21 @@ def main() -> None:
             leg["note"] = "same loop with option scan8 = 0 (bench.py --scan fp16, the default, times it as the main figure): every launch reads the fp16 rows"
             out["fp16_scan"] = leg
             int8_r = main_r
+
+        # (a') SURVEY 8(d) quotes configs[1] at k = 10 AND k = 100: the same loop at k = 100 over both operands (their own slots; the
+        #      k > 32 class of the int8 image starts on two images per query)
+        if k != 100:
+            loop100 = Loop(idx, queries, k=100)
+            k100 = {"k": 100, "steps": 100, "warmup": 20}
+            for scan in ("fp16", "int8"):
+                r100 = loop100.timed(scan, 100, 20, True)
+                t100 = r100["timing"]
+                k100[scan] = {"value": 100 * B / r100["elapsed"], "unit": "queries/s", "ms_per_step": r100["elapsed"] / 100 * 1e3,
+                              "scan_launch_us": t100["scan_ms"] * 1e3 / max(t100["scan_launches"], 1), "scanned_int8_image_in_every_timed_step": r100["int8"],
+                              "repaired_queries": r100["fixed"], "exact_scans": t100["exact_scans"], "scan8_level_after": r100["scan8_level"],
+                              "timed_path_vs_exact_fp64_scan": loop100.exact_fp64_check(r100, 2)}
+            out["k100"] = k100
+            del loop100
 
         # (b) the reference-shaped blocking calls (host buffers in, host buffers out), reported beside `value`, never as `value`
         idx.set_option("scan8", 1)          # the library's own rule, as a DenseIndex would run
