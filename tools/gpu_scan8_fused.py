@@ -26,14 +26,15 @@ def loop(steps):
     with torch.cuda.stream(st):
         for i in range(steps):
             j = i % 16
-            idx.search_hint_next_device(qs[(i + 1) % 16], 64, st.cuda_stream)
+            if os.environ.get("RQ_NOHINT") != "1":      # RQ_NOHINT=1: every call prepares its own queries (no prep workgroups in the fused launch)
+                idx.search_hint_next_device(qs[(i + 1) % 16], 64, st.cuda_stream)
             idx.search_device(qs[j], 64, k, 0, outs[j][0], outs[j][1], None, outs[j][2], st.cuda_stream)
         idx.search_flush_device(st.cuda_stream)
     torch.cuda.synchronize()
 for rep in range(2):
     for opts in sets:
         pairs = [o.split("=") for o in opts.split(",") if o]
-        idx.set_option("scan8", 1); idx.set_option("thr_mult8", 1.25); idx.set_option("tail_stop", 0)   # defaults, then the set
+        idx.set_option("scan8", 1); idx.set_option("thr_mult8", 1.25); idx.set_option("tail_stop", 0); idx.set_option("pipeline", 2)   # defaults, then the set
         for name, v in pairs:
             idx.set_option(name, float(v))
         idx.set_option("profile", 0)
