@@ -17,6 +17,7 @@ run unchanged against it.  What differs underneath:
 """
 from __future__ import annotations
 
+import gc
 import io
 import json
 import logging
@@ -713,12 +714,21 @@ class DenseIndex:
         ok = rows >= 0
         all_ok = bool(ok.all())
         safe = rows if all_ok else np.where(ok, rows, 0)
-        idl, scl = ids[safe].tolist(), scores.astype(np.float64).tolist()
-        txl = texts[safe].tolist() if texts is not None else [[""] * rows.shape[1]] * rows.shape[0]
-        if all_ok:
-            return [list(zip(i, s, t)) for i, s, t in zip(idl, scl, txl)]
-        okl = ok.tolist()
-        return [[(i, s, t) for i, s, t, v in zip(ib, sb, tb, vb) if v] for ib, sb, tb, vb in zip(idl, scl, txl, okl)]
+        # B * k tuples + B lists of (str, float, str): nothing here can form a cycle, but every 700th container allocation starts a
+        # young-generation collection -- 40 % of this function at 256 x 10 (370 -> 220 us on the build container) -- so the collector
+        # is paused for these few lines
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            idl, scl = ids[safe].tolist(), scores.astype(np.float64).tolist()
+            txl = texts[safe].tolist() if texts is not None else [[""] * rows.shape[1]] * rows.shape[0]
+            if all_ok:
+                return [list(zip(i, s, t)) for i, s, t in zip(idl, scl, txl)]
+            okl = ok.tolist()
+            return [[(i, s, t) for i, s, t, v in zip(ib, sb, tb, vb) if v] for ib, sb, tb, vb in zip(idl, scl, txl, okl)]
+        finally:
+            if gc_was_on:
+                gc.enable()
 
     def search_vectors(self, vectors: np.ndarray, top_k: int = 10) -> List[List[Tuple[str, float, str]]]:
         vectors = np.atleast_2d(np.asarray(vectors, dtype=np.float32))
