@@ -24,5 +24,5 @@ for rep in range(3):
             t_rows += t1 - t0; t_asm += t2 - t1
             dq = torch.randn((256, 768), device="cuda:0"); torch.cuda.synchronize()
             t0 = time.perf_counter(); idx.search_device_vectors(dq, 10); t_all += time.perf_counter() - t0
-        print(f"collector paused={paused}: search+D2H {t_rows * 10:.1f} us, assembly {t_asm * 10:.1f} us, search_device_vectors {t_all * 10:.1f} us", flush=True)
+        print(f"collector paused={paused}: search+D2H {t_rows * 1e4:.1f} us, assembly {t_asm * 1e4:.1f} us, search_device_vectors {t_all * 1e4:.1f} us", flush=True)
 si.gc.disable = real_disable
