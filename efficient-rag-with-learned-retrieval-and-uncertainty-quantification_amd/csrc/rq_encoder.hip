@@ -22,7 +22,7 @@
 
 #define NB_HEAD_DIM 64
 #define NB_MAX_SEQ 512      // keys one attention workgroup stages in LDS (150 KB at 512: one workgroup per CU)
-#define NB_QBLOCK 64        // queries per attention workgroup (16 per wave)
+#define NB_QBLOCK 64        // queries per 4-wave attention workgroup (16 per wave; 128 for the 8-wave form of long sequences)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Attention.  Grid (heads, batch), 256 threads: a workgroup stages the keys and values of one (sequence, head) once and walks
@@ -45,7 +45,7 @@
 //   q  [64][72]           rotated queries of this block
 // 36 KB at L = 68 (4 workgroups per CU), 80 KB at L = 256, 150 KB at L = 512 (the CU's 160 KB: one workgroup).
 #define NB_KSTRIDE (NB_HEAD_DIM + 8)
-static inline size_t nb_attn_lds_bytes(int nkmax) { return ((size_t)nkmax * NB_KSTRIDE + (size_t)NB_HEAD_DIM * (nkmax + 8) + (size_t)NB_QBLOCK * NB_KSTRIDE) * 2; }
+static inline size_t nb_attn_lds_bytes(int nkmax, int nw = 4) { return ((size_t)nkmax * NB_KSTRIDE + (size_t)NB_HEAD_DIM * (nkmax + 8) + (size_t)16 * nw * NB_KSTRIDE) * 2; }
 
 // rope[pos][0..31] = cos(pos * theta^(-d / 32)), rope[pos][32..63] = sin(...)  (fp32; the reference module rounds them to fp16)
 __global__ void rq_nb_rope_table_kernel(float* rope, int seq, float theta) {
@@ -67,7 +67,11 @@ __device__ __forceinline__ void nb_rotate8(const rq_half8 lo, const rq_half8 hi,
     }
 }
 
-__global__ __launch_bounds__(256) void rq_nb_attention_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ len, const float* __restrict__ rope,
+// NW waves per workgroup, 16 queries each.  4: sequences whose K / V^T leave room for two workgroups per CU (<= 80 KB: up to 256 tokens).
+// 8: longer ones -- their 150 KB allow ONE workgroup per CU, and four waves there are one wave per SIMD, whose QK^T -> softmax -> PV chain
+// nothing overlaps (round 3: 512-token batches).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void rq_nb_attention_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ len, const float* __restrict__ rope,
                                                               _Float16* __restrict__ ctx, int L, int H, int nkmax, float scale) {
     extern __shared__ __attribute__((aligned(16))) char nb_smem[];
     _Float16* const Sk = reinterpret_cast<_Float16*>(nb_smem);
@@ -81,11 +85,11 @@ __global__ __launch_bounds__(256) void rq_nb_attention_kernel(const _Float16* __
     const int ld = 3 * H;
     const rq_half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     // rows of padding: zero (the residual + LayerNorm that follows reads them)
-    for (int i = n * 8 + tid; i < L * 8; i += 256) *(rq_half8*)(ctx + (row0 + (i >> 3)) * H + head * NB_HEAD_DIM + (i & 7) * 8) = zero8;
+    for (int i = n * 8 + tid; i < L * 8; i += 64 * NW) *(rq_half8*)(ctx + (row0 + (i >> 3)) * H + head * NB_HEAD_DIM + (i & 7) * 8) = zero8;
     if (n == 0) return;
     const int nk = (n + 31) & ~31;                          // keys padded to whole 32-key steps (<= nkmax)
     // ---- stage K (rotated) and V^T once: 16-byte global loads, rows beyond n are zero
-    for (int i = tid; i < nk * 4; i += 256) {
+    for (int i = tid; i < nk * 4; i += 64 * NW) {
         const int r = i >> 2, j = i & 3;
         rq_half8 olo = zero8, ohi = zero8;
         if (r < n) {
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(256) void rq_nb_attention_kernel(const _Float16* __
         *(rq_half8*)(Sk + r * NB_KSTRIDE + 8 * j) = olo;
         *(rq_half8*)(Sk + r * NB_KSTRIDE + 32 + 8 * j) = ohi;
     }
-    for (int i = tid; i < nk * 8; i += 256) {
+    for (int i = tid; i < nk * 8; i += 64 * NW) {
         const int r = i >> 3, j = i & 7;
         rq_half8 v = zero8;
         if (r < n) v = *(const rq_half8*)(qkv + (row0 + r) * ld + 2 * H + head * NB_HEAD_DIM + 8 * j);
@@ -103,10 +107,10 @@ __global__ __launch_bounds__(256) void rq_nb_attention_kernel(const _Float16* __
         for (int e = 0; e < 8; ++e) Svt[(8 * j + e) * vstride + r] = v[e];
     }
     const int r16 = lane & 15, kg = lane >> 4;
-    // ---- blocks of 64 queries (16 per wave); K / V^T stay, the Q block is restaged
-    for (int q0 = 0; q0 < n; q0 += NB_QBLOCK) {
+    // ---- blocks of 16 NW queries (16 per wave); K / V^T stay, the Q block is restaged
+    for (int q0 = 0; q0 < n; q0 += 16 * NW) {
         if (q0) __syncthreads();                            // every wave is done with the previous Q block
-        for (int i = tid; i < NB_QBLOCK * 4; i += 256) {
+        for (int i = tid; i < 16 * NW * 4; i += 64 * NW) {
             const int r = i >> 2, j = i & 3, pos = q0 + r;
             rq_half8 olo = zero8, ohi = zero8;
             if (pos < n) {
@@ -287,17 +291,22 @@ extern "C" int rq_nb_attention_f16(const void* d_qkv, const int* d_len, const fl
     if (batch < 1 || batch > 65535 || heads < 1 || heads > 65535) return set_err(RQ_EINVAL, "batch %d / heads %d outside 1..65535", batch, heads);
     if (seq < 1 || seq > NB_MAX_SEQ) return set_err(RQ_EUNSUPPORTED, "sequence length %d outside 1..%d: use the framework's attention for longer inputs", seq, NB_MAX_SEQ);
     const int nkmax = (seq + 31) & ~31;
-    const size_t lds = nb_attn_lds_bytes(nkmax);
+    // two 4-wave workgroups per CU while their LDS allows it, else one of 8 waves
+    const bool wide = 2 * nb_attn_lds_bytes(nkmax, 4) > (size_t)160 * 1024;
+    const size_t lds = nb_attn_lds_bytes(nkmax, wide ? 8 : 4);
     const dim3 grid((unsigned)heads, (unsigned)batch);
     static unsigned long long attr_done = 0;   // one bit per device
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
     if (!((attr_done >> (dev & 63)) & 1ull)) {
-        HIPCHK(hipFuncSetAttribute((const void*)rq_nb_attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb_attn_lds_bytes(NB_MAX_SEQ)));
+        HIPCHK(hipFuncSetAttribute((const void*)rq_nb_attention_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb_attn_lds_bytes(NB_MAX_SEQ, 4)));
+        HIPCHK(hipFuncSetAttribute((const void*)rq_nb_attention_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb_attn_lds_bytes(NB_MAX_SEQ, 8)));
         attr_done |= 1ull << (dev & 63);
     }
-    hipLaunchKernelGGL(rq_nb_attention_kernel, grid, dim3(256), lds, (hipStream_t)stream, (const _Float16*)d_qkv, d_len, d_rope, (_Float16*)d_ctx, seq,
-                       heads * NB_HEAD_DIM, nkmax, 0.125f);
+    if (wide) hipLaunchKernelGGL(rq_nb_attention_kernel<8>, grid, dim3(512), lds, (hipStream_t)stream, (const _Float16*)d_qkv, d_len, d_rope, (_Float16*)d_ctx, seq,
+                                 heads * NB_HEAD_DIM, nkmax, 0.125f);
+    else hipLaunchKernelGGL(rq_nb_attention_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, (const _Float16*)d_qkv, d_len, d_rope, (_Float16*)d_ctx, seq,
+                            heads * NB_HEAD_DIM, nkmax, 0.125f);
     HIPCHK(hipGetLastError());
     return RQ_OK;
 }
