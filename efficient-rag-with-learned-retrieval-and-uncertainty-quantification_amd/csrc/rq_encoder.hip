@@ -21,31 +21,37 @@
 #include "rq_index.h"   // set_err, HIPCHK
 
 #define NB_HEAD_DIM 64
-#define NB_MAX_SEQ 512      // keys one attention workgroup stages in LDS (150 KB at 512: one workgroup per CU)
-#define NB_QBLOCK 64        // queries per 4-wave attention workgroup (16 per wave; 128 for the 8-wave form of long sequences)
+#define NB_MAX_SEQ 512      // keys one attention workgroup stages in LDS (137 KB at 512: one workgroup per CU)
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Attention.  Grid (heads, batch), 256 threads: a workgroup stages the keys and values of one (sequence, head) once and walks
-// over the queries in blocks of 64 (16 per wave).  qkv: [batch * L][3 * H] fp16 with H = heads * 64 (q | k | v),
-// ctx: [batch * L][H] fp16.  len[b] = valid tokens of sequence b (the first len[b] positions); rows >= len[b] of ctx are
-// written as zeros.
+// Attention.  Grid (heads, batch), NW waves: a workgroup stages the keys and values of one (sequence, head) in LDS once; its waves
+// then walk over the queries in tiles of 16 QG (wave w takes tiles w, w + NW, ..), each wave on its own -- no barrier after the
+// staging.  qkv: [batch * L][3 * H] fp16 with H = heads * 64 (q | k | v), ctx: [batch * L][H] fp16.  len[b] = valid tokens of
+// sequence b (the first len[b] positions); rows >= len[b] of ctx are written as zeros.
 //
 // Everything is computed transposed so that no operand ever needs a cross-lane transpose:
-//   S^T = K Q^T      A = K rows (lane: key r16, dims 8 kg ..), B = Q rows (lane: query r16, dims 8 kg ..)
+//   S^T = K Q^T      A = K rows (lane: key r16, dims 8 kg .. and 32 + 8 kg ..), B = Q rows (lane: query r16, the same dims): a lane's
+//                    two Q fragments are exactly one rotary pair group (d, d + 32), so the queries are rotated in registers
+//                    straight from global memory -- they never pass through LDS (round 3; before: a 64-query block staged per
+//                    barrier pair)
 //                    D[key 4 kg + i][query r16]: a lane holds 4 consecutive keys of ONE query -> the softmax statistics of a
-//                    query are lane-local sums plus two xor-shuffles (16, 32)
+//                    query are lane-local sums plus the 3 other lanes of its quad {r16 + 16 kg}: v_permlane16_swap /
+//                    v_permlane32_swap (gfx950) + one max / add each, no LDS crossbar traffic (ds_bpermute before)
 //   O^T = V^T P^T    B = P^T: the lane's own D registers of two key tiles (keys 4 kg + i of tile t0, then of tile t1) -- the
 //                    k index of an MFMA is only a label, so A = V^T is read with the SAME key order: Vt[dim][key] in LDS,
 //                    two 8-byte reads per fragment
 //                    D[dim 4 kg + i][query r16]: 4 consecutive dims of one query -> one 8-byte store
+// QG = 2: a wave carries two 16-query groups through every key step -- the K and V^T fragments are read from LDS once for
+// both (LDS reads were 70 % of their issue rate at 512 tokens) and the two QK^T -> softmax -> PV chains overlap each other.
+// exp(x - m) is exp2 of scores pre-multiplied by log2(e) / 8 (v_exp_f32 IS exp2); the running output is rescaled only in
+// key steps where some query's maximum moved.
 // ---------------------------------------------------------------------------------------------------------------------
 // LDS of one workgroup, carved at run time for the batch's padded sequence length nkmax = round32(L):
 //   k  [nkmax][72] fp16   rotated keys, row-major (rows 144 B apart: conflict-free 16-byte reads)
 //   vt [64][nkmax + 8]    values transposed
-//   q  [64][72]           rotated queries of this block
-// 36 KB at L = 68 (4 workgroups per CU), 80 KB at L = 256, 150 KB at L = 512 (the CU's 160 KB: one workgroup).
+// 27 KB at L = 68 (4+ workgroups of 4 waves per CU), 69 KB at L = 256 (two), 137 KB at L = 512 (one, of 8 waves).
 #define NB_KSTRIDE (NB_HEAD_DIM + 8)
-static inline size_t nb_attn_lds_bytes(int nkmax, int nw = 4) { return ((size_t)nkmax * NB_KSTRIDE + (size_t)NB_HEAD_DIM * (nkmax + 8) + (size_t)16 * nw * NB_KSTRIDE) * 2; }
+static inline size_t nb_attn_lds_bytes(int nkmax) { return ((size_t)nkmax * NB_KSTRIDE + (size_t)NB_HEAD_DIM * (nkmax + 8)) * 2; }
 
 // rope[pos][0..31] = cos(pos * theta^(-d / 32)), rope[pos][32..63] = sin(...)  (fp32; the reference module rounds them to fp16)
 __global__ void rq_nb_rope_table_kernel(float* rope, int seq, float theta) {
@@ -67,17 +73,28 @@ __device__ __forceinline__ void nb_rotate8(const rq_half8 lo, const rq_half8 hi,
     }
 }
 
-// NW waves per workgroup, 16 queries each.  4: sequences whose K / V^T leave room for two workgroups per CU (<= 80 KB: up to 256 tokens).
-// 8: longer ones -- their 150 KB allow ONE workgroup per CU, and four waves there are one wave per SIMD, whose QK^T -> softmax -> PV chain
-// nothing overlaps (round 3: 512-token batches).
-template <int NW>
+// max / sum over the 4 lanes {r16 + 16 kg} that share a query: the two swaps leave, in every lane, its own row's value in one result and
+// the partner row's in the other (rows of 16 lanes, then halves of 32)
+__device__ __forceinline__ float nb_quad_max(float v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float nb_quad_sum(float v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+template <int NW, int QG>
 __global__ __launch_bounds__(64 * NW) void rq_nb_attention_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ len, const float* __restrict__ rope,
-                                                              _Float16* __restrict__ ctx, int L, int H, int nkmax, float scale) {
+                                                                  _Float16* __restrict__ ctx, int L, int H, int nkmax, float scale_log2e) {
     extern __shared__ __attribute__((aligned(16))) char nb_smem[];
     _Float16* const Sk = reinterpret_cast<_Float16*>(nb_smem);
     const int vstride = nkmax + 8;
     _Float16* const Svt = Sk + (size_t)nkmax * NB_KSTRIDE;
-    _Float16* const Sq = Svt + (size_t)NB_HEAD_DIM * vstride;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int head = blockIdx.x, b = blockIdx.y;
     const int n = len[b] < L ? len[b] : L;                 // valid tokens (keys) of this sequence
@@ -106,85 +123,92 @@ __global__ __launch_bounds__(64 * NW) void rq_nb_attention_kernel(const _Float16
 #pragma unroll
         for (int e = 0; e < 8; ++e) Svt[(8 * j + e) * vstride + r] = v[e];
     }
+    __syncthreads();                                        // the only barrier: K and V^T are read-only from here on
     const int r16 = lane & 15, kg = lane >> 4;
-    // ---- blocks of 16 NW queries (16 per wave); K / V^T stay, the Q block is restaged
-    for (int q0 = 0; q0 < n; q0 += 16 * NW) {
-        if (q0) __syncthreads();                            // every wave is done with the previous Q block
-        for (int i = tid; i < 16 * NW * 4; i += 64 * NW) {
-            const int r = i >> 2, j = i & 3, pos = q0 + r;
-            rq_half8 olo = zero8, ohi = zero8;
+    // ---- query tiles of 16 QG, one wave each
+    for (int q0 = 16 * QG * wave; q0 < n; q0 += 16 * QG * NW) {
+        // B operand of S^T = K Q^T: query q0 + 16 g + r16, dims 8 kg .. (k-step 0) and 32 + 8 kg .. (k-step 1), rotated here
+        rq_half8 qf0[QG], qf1[QG];
+        float m[QG], l[QG];                                 // running max / sum of this lane's query (identical on its 4 lanes)
+        rq_float4 o[QG][4];
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+            const int pos = q0 + 16 * g + r16;
+            qf0[g] = zero8; qf1[g] = zero8;
             if (pos < n) {
-                const _Float16* p = qkv + (row0 + pos) * ld + head * NB_HEAD_DIM + 8 * j;
-                nb_rotate8(*(const rq_half8*)p, *(const rq_half8*)(p + 32), rope + pos * 64 + 8 * j, olo, ohi);
+                const _Float16* p = qkv + (row0 + pos) * ld + head * NB_HEAD_DIM + 8 * kg;
+                nb_rotate8(*(const rq_half8*)p, *(const rq_half8*)(p + 32), rope + pos * 64 + 8 * kg, qf0[g], qf1[g]);
             }
-            *(rq_half8*)(Sq + r * NB_KSTRIDE + 8 * j) = olo;
-            *(rq_half8*)(Sq + r * NB_KSTRIDE + 32 + 8 * j) = ohi;
+            m[g] = -__builtin_huge_valf(); l[g] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) o[g][t] = rq_float4{0.f, 0.f, 0.f, 0.f};
         }
-        __syncthreads();
-        if (q0 + 16 * wave >= n) continue;                  // (uniform per wave) none of this wave's 16 queries is a token
-        // B operand of S^T = K Q^T: this wave's 16 queries, dims 8 kg .. (k-steps 0 and 1)
-        const rq_half8 qf0 = *(const rq_half8*)(Sq + (16 * wave + r16) * NB_KSTRIDE + 8 * kg);
-        const rq_half8 qf1 = *(const rq_half8*)(Sq + (16 * wave + r16) * NB_KSTRIDE + 32 + 8 * kg);
-        float m = -__builtin_huge_valf(), l = 0.f;          // running max / sum of this lane's query (identical on its 4 lanes)
-        rq_float4 o[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         for (int k0 = 0; k0 < nk; k0 += 32) {
-            rq_float4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-            {
-                const _Float16* kr = Sk + (k0 + r16) * NB_KSTRIDE + 8 * kg;
-                const rq_half8 a00 = *(const rq_half8*)kr, a01 = *(const rq_half8*)(kr + 32);
-                const rq_half8 a10 = *(const rq_half8*)(kr + 16 * NB_KSTRIDE), a11 = *(const rq_half8*)(kr + 16 * NB_KSTRIDE + 32);
-                s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a00, qf0, s0, 0, 0, 0);
-                s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a01, qf1, s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a10, qf0, s1, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a11, qf1, s1, 0, 0, 0);
-            }
-            // scale, prefix mask, online softmax over this lane's 8 keys + the 3 other lanes of the query
-            float sv[8], mx = -__builtin_huge_valf();
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                sv[i] = (k0 + 4 * kg + i < n) ? s0[i] * scale : -__builtin_huge_valf();
-                sv[4 + i] = (k0 + 16 + 4 * kg + i < n) ? s1[i] * scale : -__builtin_huge_valf();
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) mx = fmaxf(mx, sv[i]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mn = fmaxf(m, mx);                  // finite: key 0 is always valid (n >= 1)
-            const float alpha = __expf(m - mn);
-            float ps = 0.f;
-            rq_half8 pf;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float p = __expf(sv[i] - mn);         // exp(-inf) = 0 for masked keys
-                ps += p;
-                pf[i] = (_Float16)p;
-            }
-            ps += __shfl_xor(ps, 16, 64);
-            ps += __shfl_xor(ps, 32, 64);
-            l = l * alpha + ps;
-            m = mn;
-            // O^T += V^T P^T: A fragment of dim tile t = Vt[16 t + r16][keys 4 kg .. of tile k0, then of tile k0 + 16]
+            const _Float16* kr = Sk + (k0 + r16) * NB_KSTRIDE + 8 * kg;
+            const rq_half8 a00 = *(const rq_half8*)kr, a01 = *(const rq_half8*)(kr + 32);
+            const rq_half8 a10 = *(const rq_half8*)(kr + 16 * NB_KSTRIDE), a11 = *(const rq_half8*)(kr + 16 * NB_KSTRIDE + 32);
+            // A fragment of dim tile t of O^T += V^T P^T: Vt[16 t + r16][keys 4 kg .. of tile k0, then of tile k0 + 16]
+            rq_half8 vf[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const rq_half4 v0 = *(const rq_half4*)(Svt + (16 * t + r16) * vstride + k0 + 4 * kg);
                 const rq_half4 v1 = *(const rq_half4*)(Svt + (16 * t + r16) * vstride + k0 + 16 + 4 * kg);
-                const rq_half8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                vf[t] = rq_half8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            }
+            const bool full = k0 + 32 <= n;                 // (uniform) no masked key in this step
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o[t][i] *= alpha;
-                o[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[t], 0, 0, 0);
+            for (int g = 0; g < QG; ++g) {
+                rq_float4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+                s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a00, qf0[g], s0, 0, 0, 0);
+                s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a01, qf1[g], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a10, qf0[g], s1, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a11, qf1[g], s1, 0, 0, 0);
+                // scale (log2 domain), prefix mask, online softmax over this lane's 8 keys + the 3 other lanes of the query
+                float sv[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    sv[i] = (full || k0 + 4 * kg + i < n) ? s0[i] * scale_log2e : -__builtin_huge_valf();
+                    sv[4 + i] = (full || k0 + 16 + 4 * kg + i < n) ? s1[i] * scale_log2e : -__builtin_huge_valf();
+                }
+                float mx = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+                mx = nb_quad_max(mx);
+                const float mn = fmaxf(m[g], mx);           // finite: key 0 is always valid (n >= 1)
+                const float alpha = __builtin_amdgcn_exp2f(m[g] - mn);
+                float ps = 0.f;
+                rq_half8 pf;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float p = __builtin_amdgcn_exp2f(sv[i] - mn);   // exp2(-inf) = 0 for masked keys
+                    ps += p;
+                    pf[i] = (_Float16)p;
+                }
+                ps = nb_quad_sum(ps);
+                l[g] = l[g] * alpha + ps;
+                m[g] = mn;
+                if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {      // some query's maximum moved: rescale the running output
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o[g][t][i] *= alpha;
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[t], pf, o[g][t], 0, 0, 0);
             }
         }
         // ---- O[query][dim 16 t + 4 kg + i] = o[t][i] / l
-        const int pos = q0 + 16 * wave + r16;
-        if (pos < n) {
-            const float inv = 1.f / l;
-            _Float16* dst = ctx + (row0 + pos) * H + head * NB_HEAD_DIM + 4 * kg;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                rq_half4 h;
+        for (int g = 0; g < QG; ++g) {
+            const int pos = q0 + 16 * g + r16;
+            if (pos < n) {
+                const float inv = 1.f / l[g];
+                _Float16* dst = ctx + (row0 + pos) * H + head * NB_HEAD_DIM + 4 * kg;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) h[i] = (_Float16)(o[t][i] * inv);
-                *(rq_half4*)(dst + 16 * t) = h;
+                for (int t = 0; t < 4; ++t) {
+                    rq_half4 h;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) h[i] = (_Float16)(o[g][t][i] * inv);
+                    *(rq_half4*)(dst + 16 * t) = h;
+                }
             }
         }
     }
@@ -291,22 +315,27 @@ extern "C" int rq_nb_attention_f16(const void* d_qkv, const int* d_len, const fl
     if (batch < 1 || batch > 65535 || heads < 1 || heads > 65535) return set_err(RQ_EINVAL, "batch %d / heads %d outside 1..65535", batch, heads);
     if (seq < 1 || seq > NB_MAX_SEQ) return set_err(RQ_EUNSUPPORTED, "sequence length %d outside 1..%d: use the framework's attention for longer inputs", seq, NB_MAX_SEQ);
     const int nkmax = (seq + 31) & ~31;
-    // two 4-wave workgroups per CU while their LDS allows it, else one of 8 waves
-    const bool wide = 2 * nb_attn_lds_bytes(nkmax, 4) > (size_t)160 * 1024;
-    const size_t lds = nb_attn_lds_bytes(nkmax, wide ? 8 : 4);
+    // two or more 4-wave workgroups per CU while their LDS allows it, else one of 8 waves; two query groups per wave from 129 tokens on
+    // (below that a sequence has too few 32-query tiles for its waves)
+    const size_t lds = nb_attn_lds_bytes(nkmax);
+    const int form = 2 * lds > (size_t)160 * 1024 ? 2 : (seq > 128 ? 1 : 0);
     const dim3 grid((unsigned)heads, (unsigned)batch);
     static unsigned long long attr_done = 0;   // one bit per device
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
     if (!((attr_done >> (dev & 63)) & 1ull)) {
-        HIPCHK(hipFuncSetAttribute((const void*)rq_nb_attention_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb_attn_lds_bytes(NB_MAX_SEQ, 4)));
-        HIPCHK(hipFuncSetAttribute((const void*)rq_nb_attention_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb_attn_lds_bytes(NB_MAX_SEQ, 8)));
+        HIPCHK(hipFuncSetAttribute((const void*)rq_nb_attention_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb_attn_lds_bytes(NB_MAX_SEQ)));
+        HIPCHK(hipFuncSetAttribute((const void*)rq_nb_attention_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb_attn_lds_bytes(NB_MAX_SEQ)));
+        HIPCHK(hipFuncSetAttribute((const void*)rq_nb_attention_kernel<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb_attn_lds_bytes(NB_MAX_SEQ)));
         attr_done |= 1ull << (dev & 63);
     }
-    if (wide) hipLaunchKernelGGL(rq_nb_attention_kernel<8>, grid, dim3(512), lds, (hipStream_t)stream, (const _Float16*)d_qkv, d_len, d_rope, (_Float16*)d_ctx, seq,
-                                 heads * NB_HEAD_DIM, nkmax, 0.125f);
-    else hipLaunchKernelGGL(rq_nb_attention_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, (const _Float16*)d_qkv, d_len, d_rope, (_Float16*)d_ctx, seq,
-                            heads * NB_HEAD_DIM, nkmax, 0.125f);
+    const float scale_log2e = 0.125f * 1.4426950408889634f;      // 1 / sqrt(64), in the log2 domain of v_exp_f32
+#define NB_ATTN_LAUNCH(NW_, QG_) hipLaunchKernelGGL((rq_nb_attention_kernel<NW_, QG_>), grid, dim3(64 * NW_), lds, (hipStream_t)stream, (const _Float16*)d_qkv, d_len, \
+                                                    d_rope, (_Float16*)d_ctx, seq, heads * NB_HEAD_DIM, nkmax, scale_log2e)
+    if (form == 2) NB_ATTN_LAUNCH(8, 2);
+    else if (form == 1) NB_ATTN_LAUNCH(4, 2);
+    else NB_ATTN_LAUNCH(4, 1);
+#undef NB_ATTN_LAUNCH
     HIPCHK(hipGetLastError());
     return RQ_OK;
 }
