@@ -88,6 +88,8 @@ __device__ __forceinline__ float nb_quad_sum(float v) {
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+template <bool V> struct NbBool { static constexpr bool value = V; };
+
 template <int NW, int QG>
 __global__ __launch_bounds__(64 * NW) void rq_nb_attention_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ len, const float* __restrict__ rope,
                                                                   _Float16* __restrict__ ctx, int L, int H, int nkmax, float scale_log2e) {
@@ -143,7 +145,9 @@ __global__ __launch_bounds__(64 * NW) void rq_nb_attention_kernel(const _Float16
 #pragma unroll
             for (int t = 0; t < 4; ++t) o[g][t] = rq_float4{0.f, 0.f, 0.f, 0.f};
         }
-        for (int k0 = 0; k0 < nk; k0 += 32) {
+        // one step of 32 keys; MASK: the sequence ends inside this step (only the last one can: nk = round32(n))
+        auto step = [&](auto mask_tag, const int k0) {
+            constexpr bool MASK = decltype(mask_tag)::value;
             const _Float16* kr = Sk + (k0 + r16) * NB_KSTRIDE + 8 * kg;
             const rq_half8 a00 = *(const rq_half8*)kr, a01 = *(const rq_half8*)(kr + 32);
             const rq_half8 a10 = *(const rq_half8*)(kr + 16 * NB_KSTRIDE), a11 = *(const rq_half8*)(kr + 16 * NB_KSTRIDE + 32);
@@ -155,7 +159,6 @@ __global__ __launch_bounds__(64 * NW) void rq_nb_attention_kernel(const _Float16
                 const rq_half4 v1 = *(const rq_half4*)(Svt + (16 * t + r16) * vstride + k0 + 16 + 4 * kg);
                 vf[t] = rq_half8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
             }
-            const bool full = k0 + 32 <= n;                 // (uniform) no masked key in this step
 #pragma unroll
             for (int g = 0; g < QG; ++g) {
                 rq_float4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
@@ -163,22 +166,25 @@ __global__ __launch_bounds__(64 * NW) void rq_nb_attention_kernel(const _Float16
                 s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a01, qf1[g], s0, 0, 0, 0);
                 s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a10, qf0[g], s1, 0, 0, 0);
                 s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a11, qf1[g], s1, 0, 0, 0);
-                // scale (log2 domain), prefix mask, online softmax over this lane's 8 keys + the 3 other lanes of the query
-                float sv[8];
+                // prefix mask, online softmax over this lane's 8 keys + the 3 other lanes of the query.  The maximum is taken over the raw
+                // dot products (the scale is positive) and exp2(s c - m) is one fma + v_exp_f32 per key
+                float sv[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+                if constexpr (MASK) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    sv[i] = (full || k0 + 4 * kg + i < n) ? s0[i] * scale_log2e : -__builtin_huge_valf();
-                    sv[4 + i] = (full || k0 + 16 + 4 * kg + i < n) ? s1[i] * scale_log2e : -__builtin_huge_valf();
+                    for (int i = 0; i < 4; ++i) {
+                        if (k0 + 4 * kg + i >= n) sv[i] = -__builtin_huge_valf();
+                        if (k0 + 16 + 4 * kg + i >= n) sv[4 + i] = -__builtin_huge_valf();
+                    }
                 }
                 float mx = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
                 mx = nb_quad_max(mx);
-                const float mn = fmaxf(m[g], mx);           // finite: key 0 is always valid (n >= 1)
+                const float mn = fmaxf(m[g], mx * scale_log2e);   // finite: key 0 is always valid (n >= 1); -inf * c = -inf
                 const float alpha = __builtin_amdgcn_exp2f(m[g] - mn);
                 float ps = 0.f;
                 rq_half8 pf;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const float p = __builtin_amdgcn_exp2f(sv[i] - mn);   // exp2(-inf) = 0 for masked keys
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[i], scale_log2e, -mn));   // exp2(-inf) = 0 for masked keys
                     ps += p;
                     pf[i] = (_Float16)p;
                 }
@@ -194,7 +200,10 @@ __global__ __launch_bounds__(64 * NW) void rq_nb_attention_kernel(const _Float16
 #pragma unroll
                 for (int t = 0; t < 4; ++t) o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[t], pf, o[g][t], 0, 0, 0);
             }
-        }
+        };
+        int k0 = 0;
+        for (; k0 + 32 <= n; k0 += 32) step(NbBool<false>{}, k0);
+        if (k0 < nk) step(NbBool<true>{}, k0);
         // ---- O[query][dim 16 t + 4 kg + i] = o[t][i] / l
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
