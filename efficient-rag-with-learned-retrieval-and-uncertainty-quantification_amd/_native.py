@@ -66,6 +66,8 @@ _SIGNATURES = {
     "rq_nb_add_layernorm_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p]),
     "rq_nb_swiglu_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "rq_nb_mean_pool_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "rq_nb_attention_packed_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "rq_nb_mean_pool_packed_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "rq_search_hint_next_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "rq_stream_release": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rq_merge_keys_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -313,6 +315,11 @@ def nb_attention(qkv, lengths, rope, ctx, batch: int, seq: int, heads: int, stre
                                               C.c_void_p(stream)), "rq_nb_attention_f16")
 
 
+def nb_attention_packed(qkv, offsets, rope, ctx, batch: int, max_seq: int, heads: int, stream: int = 0) -> None:
+    _check(load_library().rq_nb_attention_packed_f16(_ptr(qkv), _ptr(offsets), _ptr(rope), _ptr(ctx), int(batch), int(max_seq), int(heads),
+                                                     C.c_void_p(stream)), "rq_nb_attention_packed_f16")
+
+
 def nb_add_layernorm(x, res, gamma, beta, out, rows: int, width: int, eps: float, stream: int = 0) -> None:
     _check(load_library().rq_nb_add_layernorm_f16(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(out), int(rows), int(width), float(eps),
                                                   C.c_void_p(stream)), "rq_nb_add_layernorm_f16")
@@ -325,6 +332,11 @@ def nb_swiglu(gate_up, out, rows: int, inter: int, stream: int = 0) -> None:
 def nb_mean_pool(h, lengths, out, batch: int, seq: int, width: int, stream: int = 0) -> None:
     _check(load_library().rq_nb_mean_pool_f16(_ptr(h), _ptr(lengths), _ptr(out), int(batch), int(seq), int(width), C.c_void_p(stream)),
            "rq_nb_mean_pool_f16")
+
+
+def nb_mean_pool_packed(h, offsets, out, batch: int, max_seq: int, width: int, stream: int = 0) -> None:
+    _check(load_library().rq_nb_mean_pool_packed_f16(_ptr(h), _ptr(offsets), _ptr(out), int(batch), int(max_seq), int(width), C.c_void_p(stream)),
+           "rq_nb_mean_pool_packed_f16")
 
 
 def merge_keys_device(d_keys_in, n_per_query: int, B: int, k: int, d_scores, d_rows, d_keys_out=None, stream: int = 0) -> None:

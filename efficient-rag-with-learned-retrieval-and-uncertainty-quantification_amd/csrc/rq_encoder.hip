@@ -92,20 +92,24 @@ template <bool V> struct NbBool { static constexpr bool value = V; };
 
 template <int NW, int QG>
 __global__ __launch_bounds__(64 * NW) void rq_nb_attention_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ len, const float* __restrict__ rope,
-                                                                  _Float16* __restrict__ ctx, int L, int H, int nkmax, float scale_log2e) {
+                                                                  _Float16* __restrict__ ctx, int L, int H, int nkmax, float scale_log2e, int packed) {
     extern __shared__ __attribute__((aligned(16))) char nb_smem[];
     _Float16* const Sk = reinterpret_cast<_Float16*>(nb_smem);
     const int vstride = nkmax + 8;
     _Float16* const Svt = Sk + (size_t)nkmax * NB_KSTRIDE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int head = blockIdx.x, b = blockIdx.y;
-    const int n = len[b] < L ? len[b] : L;                 // valid tokens (keys) of this sequence
-    const size_t row0 = (size_t)b * L;
+    // padded batches: len[b] = valid tokens of sequence b, whose rows start at b * L.  Packed batches (no padding rows at all): len[] is the
+    // offset table, sequence b = rows [len[b], len[b + 1])
+    const int nraw = packed ? len[b + 1] - len[b] : len[b];
+    const int n = nraw < L ? nraw : L;                      // valid tokens (keys) of this sequence
+    const size_t row0 = packed ? (size_t)len[b] : (size_t)b * L;
     const int ld = 3 * H;
     const rq_half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     // rows of padding: zero (the residual + LayerNorm that follows reads them)
-    for (int i = n * 8 + tid; i < L * 8; i += 64 * NW) *(rq_half8*)(ctx + (row0 + (i >> 3)) * H + head * NB_HEAD_DIM + (i & 7) * 8) = zero8;
-    if (n == 0) return;
+    if (!packed)
+        for (int i = n * 8 + tid; i < L * 8; i += 64 * NW) *(rq_half8*)(ctx + (row0 + (i >> 3)) * H + head * NB_HEAD_DIM + (i & 7) * 8) = zero8;
+    if (n <= 0) return;
     const int nk = (n + 31) & ~31;                          // keys padded to whole 32-key steps (<= nkmax)
     // ---- stage K (rotated) and V^T once: 16-byte global loads, rows beyond n are zero
     for (int i = tid; i < nk * 4; i += 64 * NW) {
@@ -292,13 +296,16 @@ __global__ __launch_bounds__(256) void rq_nb_swiglu_kernel(const _Float16* __res
 }
 
 // out[b][d] = sum over the first len[b] tokens of h[b][t][d] / max(len[b], 1), fp32.  Grid (batch), 256 threads; width <= 2048.
-__global__ __launch_bounds__(256) void rq_nb_mean_pool_kernel(const _Float16* __restrict__ h, const int* __restrict__ len, float* __restrict__ out, int L, int width) {
+// packed: len[] is the offset table of a batch without padding rows (sequence b = rows [len[b], len[b + 1])).
+__global__ __launch_bounds__(256) void rq_nb_mean_pool_kernel(const _Float16* __restrict__ h, const int* __restrict__ len, float* __restrict__ out, int L, int width, int packed) {
     const int b = blockIdx.x;
-    const int n = len[b] < L ? len[b] : L;
+    const int nraw = packed ? len[b + 1] - len[b] : len[b];
+    const int n = nraw < L ? nraw : L;
+    h += (packed ? (size_t)len[b] : (size_t)b * L) * width;
     for (int c = threadIdx.x * 8; c < width; c += 256 * 8) {
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int t = 0; t < n; ++t) {
-            const rq_half8 v = *(const rq_half8*)(h + ((size_t)b * L + t) * width + c);
+            const rq_half8 v = *(const rq_half8*)(h + (size_t)t * width + c);
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
         }
@@ -319,7 +326,7 @@ extern "C" int rq_nb_rope_table_f32(float* d_rope, int seq, float rope_theta, vo
     return RQ_OK;
 }
 
-extern "C" int rq_nb_attention_f16(const void* d_qkv, const int* d_len, const float* d_rope, void* d_ctx, int batch, int seq, int heads, void* stream) {
+static int nb_attention_common(const void* d_qkv, const int* d_len, const float* d_rope, void* d_ctx, int batch, int seq, int heads, void* stream, int packed) {
     if (!d_qkv || !d_len || !d_rope || !d_ctx) return set_err(RQ_EINVAL, "null argument");
     if (batch < 1 || batch > 65535 || heads < 1 || heads > 65535) return set_err(RQ_EINVAL, "batch %d / heads %d outside 1..65535", batch, heads);
     if (seq < 1 || seq > NB_MAX_SEQ) return set_err(RQ_EUNSUPPORTED, "sequence length %d outside 1..%d: use the framework's attention for longer inputs", seq, NB_MAX_SEQ);
@@ -340,13 +347,21 @@ extern "C" int rq_nb_attention_f16(const void* d_qkv, const int* d_len, const fl
     }
     const float scale_log2e = 0.125f * 1.4426950408889634f;      // 1 / sqrt(64), in the log2 domain of v_exp_f32
 #define NB_ATTN_LAUNCH(NW_, QG_) hipLaunchKernelGGL((rq_nb_attention_kernel<NW_, QG_>), grid, dim3(64 * NW_), lds, (hipStream_t)stream, (const _Float16*)d_qkv, d_len, \
-                                                    d_rope, (_Float16*)d_ctx, seq, heads * NB_HEAD_DIM, nkmax, scale_log2e)
+                                                    d_rope, (_Float16*)d_ctx, seq, heads * NB_HEAD_DIM, nkmax, scale_log2e, packed)
     if (form == 2) NB_ATTN_LAUNCH(8, 2);
     else if (form == 1) NB_ATTN_LAUNCH(4, 2);
     else NB_ATTN_LAUNCH(4, 1);
 #undef NB_ATTN_LAUNCH
     HIPCHK(hipGetLastError());
     return RQ_OK;
+}
+
+extern "C" int rq_nb_attention_f16(const void* d_qkv, const int* d_len, const float* d_rope, void* d_ctx, int batch, int seq, int heads, void* stream) {
+    return nb_attention_common(d_qkv, d_len, d_rope, d_ctx, batch, seq, heads, stream, 0);
+}
+
+extern "C" int rq_nb_attention_packed_f16(const void* d_qkv, const int* d_offsets, const float* d_rope, void* d_ctx, int batch, int max_seq, int heads, void* stream) {
+    return nb_attention_common(d_qkv, d_offsets, d_rope, d_ctx, batch, max_seq, heads, stream, 1);
 }
 
 extern "C" int rq_nb_add_layernorm_f16(const void* d_x, const void* d_res, const void* d_gamma, const void* d_beta, void* d_out, int64_t rows, int width,
@@ -372,7 +387,15 @@ extern "C" int rq_nb_swiglu_f16(const void* d_gate_up, void* d_out, int64_t rows
 extern "C" int rq_nb_mean_pool_f16(const void* d_h, const int* d_len, float* d_out, int batch, int seq, int width, void* stream) {
     if (!d_h || !d_len || !d_out) return set_err(RQ_EINVAL, "null argument");
     if (batch < 1 || seq < 1 || width < 8 || width > 2048 || width % 8) return set_err(RQ_EINVAL, "batch %d / seq %d / width %d", batch, seq, width);
-    hipLaunchKernelGGL(rq_nb_mean_pool_kernel, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, (const _Float16*)d_h, d_len, d_out, seq, width);
+    hipLaunchKernelGGL(rq_nb_mean_pool_kernel, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, (const _Float16*)d_h, d_len, d_out, seq, width, 0);
+    HIPCHK(hipGetLastError());
+    return RQ_OK;
+}
+
+extern "C" int rq_nb_mean_pool_packed_f16(const void* d_h, const int* d_offsets, float* d_out, int batch, int max_seq, int width, void* stream) {
+    if (!d_h || !d_offsets || !d_out) return set_err(RQ_EINVAL, "null argument");
+    if (batch < 1 || max_seq < 1 || width < 8 || width > 2048 || width % 8) return set_err(RQ_EINVAL, "batch %d / max_seq %d / width %d", batch, max_seq, width);
+    hipLaunchKernelGGL(rq_nb_mean_pool_kernel, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, (const _Float16*)d_h, d_offsets, d_out, max_seq, width, 1);
     HIPCHK(hipGetLastError());
     return RQ_OK;
 }

@@ -90,6 +90,7 @@ class FusedNomicBertForward:
     """
 
     MAX_SEQ = 512
+    PACK_BELOW_PERCENT = 97        # batches with less than 3 % padding rows keep the padded layout
 
     def __init__(self, model):
         import torch
@@ -135,10 +136,24 @@ class FusedNomicBertForward:
         torch, nat = self.torch, self.nat
         F = torch.nn.functional
         B, L = ids.shape
-        T, H = B * L, self.hidden
+        H = self.hidden
         st = torch.cuda.current_stream(ids.device).cuda_stream
         lengths = mask.sum(1).to(torch.int32).contiguous()
-        h = self.emb(input_ids=ids, position_ids=torch.arange(L, device=ids.device)[None, :]).reshape(T, H).contiguous()
+        pos = torch.arange(L, device=ids.device)[None, :]
+        # Ragged batches run PACKED: the token rows of all sequences back to back (no padding rows), an offset table instead of the
+        # lengths -- GEMMs, LayerNorm and SwiGLU then work on sum(lengths) rows instead of B * longest.  (Batches that are all but full
+        # keep the padded layout: the gather below is not free.)
+        total = int(lengths.sum())
+        packed = total * 100 <= B * L * self.PACK_BELOW_PERCENT
+        if packed:
+            keep = mask.bool()
+            offs = torch.zeros((B + 1,), device=ids.device, dtype=torch.int32)
+            offs[1:] = torch.cumsum(lengths, 0)
+            T = total
+            h = self.emb(input_ids=ids[keep][None, :], position_ids=pos.expand(B, L)[keep][None, :]).reshape(T, H).contiguous()
+        else:
+            T = B * L
+            h = self.emb(input_ids=ids, position_ids=pos).reshape(T, H).contiguous()
         if self._rope is None or self._rope.device != ids.device:
             self._rope = torch.empty((self.MAX_SEQ, 64), device=ids.device, dtype=torch.float32)
             nat.nb_rope_table(self._rope, self.MAX_SEQ, self.theta, st)
@@ -146,7 +161,10 @@ class FusedNomicBertForward:
         act = torch.empty((T, self.inter), device=ids.device, dtype=torch.float16)
         for w in self.layers:
             qkv = F.linear(h, w["wqkv"])
-            nat.nb_attention(qkv, lengths, self._rope, ctx, B, L, self.heads, st)
+            if packed:
+                nat.nb_attention_packed(qkv, offs, self._rope, ctx, B, L, self.heads, st)
+            else:
+                nat.nb_attention(qkv, lengths, self._rope, ctx, B, L, self.heads, st)
             o = F.linear(ctx, w["wo"])
             nat.nb_add_layernorm(o, h, w["g1"], w["b1"], h, T, H, self.eps, st)
             gu = F.linear(h, w["wgu"])
@@ -154,7 +172,10 @@ class FusedNomicBertForward:
             d = F.linear(act, w["wd"])
             nat.nb_add_layernorm(d, h, w["g2"], w["b2"], h, T, H, self.eps, st)
         out = torch.empty((B, H), device=ids.device, dtype=torch.float32)
-        nat.nb_mean_pool(h, lengths, out, B, L, H, st)
+        if packed:
+            nat.nb_mean_pool_packed(h, offs, out, B, L, H, st)
+        else:
+            nat.nb_mean_pool(h, lengths, out, B, L, H, st)
         return out
 
 

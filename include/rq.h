@@ -213,6 +213,10 @@ int rq_nb_rope_table_f32(float* d_rope, int seq, float rope_theta, void* stream)
  * rotary = rotate-half over the 64 dims with d_rope (at least seq rows).  seq <= 512 (RQ_EUNSUPPORTED beyond: use the
  * framework's attention). */
 int rq_nb_attention_f16(const void* d_qkv, const int* d_len, const float* d_rope, void* d_ctx, int batch, int seq, int heads, void* stream);
+/* The same for a PACKED batch -- no padding rows: the tokens of sequence b are rows [d_offsets[b], d_offsets[b + 1]) of d_qkv and d_ctx
+ * (d_offsets: batch + 1 ascending ints, d_offsets[0] = 0), every sequence at most max_seq <= 512 tokens long.  The GEMMs around the
+ * attention then run on sum(lengths) rows instead of batch * longest. */
+int rq_nb_attention_packed_f16(const void* d_qkv, const int* d_offsets, const float* d_rope, void* d_ctx, int batch, int max_seq, int heads, void* stream);
 /* out = LayerNorm(x + res) * gamma + beta over rows of `width` (8..1536, multiple of 8) elements, fp32 statistics; res may be
  * NULL; out may alias x or res. */
 int rq_nb_add_layernorm_f16(const void* d_x, const void* d_res, const void* d_gamma, const void* d_beta, void* d_out, int64_t rows, int width,
@@ -221,6 +225,8 @@ int rq_nb_add_layernorm_f16(const void* d_x, const void* d_res, const void* d_ga
 int rq_nb_swiglu_f16(const void* d_gate_up, void* d_out, int64_t rows, int inter, void* stream);
 /* d_out[b][:] (fp32) = mean of d_h[b][t][:] over the first d_len[b] tokens (0 for an empty sequence). */
 int rq_nb_mean_pool_f16(const void* d_h, const int* d_len, float* d_out, int batch, int seq, int width, void* stream);
+/* ... of a packed batch: d_out[b][:] = mean of the rows [d_offsets[b], d_offsets[b + 1]) of d_h. */
+int rq_nb_mean_pool_packed_f16(const void* d_h, const int* d_offsets, float* d_out, int batch, int max_seq, int width, void* stream);
 
 #ifdef __cplusplus
 }

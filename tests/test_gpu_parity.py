@@ -1487,6 +1487,14 @@ def test_encoder_kernels_match_fp32_torch_references():
         got = ctx.float().view(B, L, H)
         assert torch.isfinite(got).all()
         assert float((got - ref).abs().max()) <= 2e-3 * max(1.0, float(ref.abs().max())), (B, L, heads, float((got - ref).abs().max()))
+        # the PACKED form (round 3: no padding rows, an offset table): the same valid rows, bit for bit
+        keep = keymask.reshape(-1)
+        offs = torch.zeros((B + 1,), device=dev, dtype=torch.int32); offs[1:] = torch.cumsum(lens, 0)
+        qkv_p = qkv[keep].contiguous()
+        ctx_p = torch.full((int(offs[-1]) + 1, H), 7.0, device=dev, dtype=torch.float16)          # (+1: a guard row that must stay untouched)
+        nat.nb_attention_packed(qkv_p, offs, rope, ctx_p, B, L, heads)
+        torch.cuda.synchronize()
+        assert torch.equal(ctx_p[:-1], ctx[keep]) and bool((ctx_p[-1] == 7.0).all()), (B, L, heads)
     rows, width = 1000, 768
     xx = torch.randn((rows, width), device=dev, generator=g).half(); rr = (torch.randn((rows, width), device=dev, generator=g) * 3).half()
     gam = (1 + 0.1 * torch.randn((width,), device=dev, generator=g)).half(); bet = (0.1 * torch.randn((width,), device=dev, generator=g)).half()
@@ -1508,6 +1516,11 @@ def test_encoder_kernels_match_fp32_torch_references():
     mk = (torch.arange(50, device=dev)[None, :] < ln[:, None]).float()[:, :, None]
     ref = (hh.float() * mk).sum(1) / mk.sum(1).clamp_min(1.0)
     assert float((pooled - ref).abs().max()) <= 1e-5
+    mkb = mk[:, :, 0].bool()
+    offs = torch.zeros((5,), device=dev, dtype=torch.int32); offs[1:] = torch.cumsum(ln, 0)
+    pooled_p = torch.empty((4, 768), device=dev)
+    nat.nb_mean_pool_packed(hh[mkb].contiguous(), offs, pooled_p, 4, 50, 768)
+    assert torch.equal(pooled_p, pooled)
     with pytest.raises(nat.RqError):
         nat.nb_attention(qkv, lens, rope, ctx, 1, 513, 1)                                   # longer than one workgroup stages
 
@@ -1515,7 +1528,8 @@ def test_encoder_kernels_match_fp32_torch_references():
 def test_fused_nomic_bert_forward_matches_the_stock_module():
     """embedders.FusedNomicBertForward (four GEMMs per layer + the fused kernels) against the stock `transformers` forward of
     the SAME fp16 weights on the same tokens: ragged lengths 1..200 in length-sorted batches, 4 layers -- per-text cosine >=
-    0.9999; 300- and 400-token texts take the fused path too (one workgroup stages up to 512 keys)."""
+    0.9999; 300- and 400-token texts take the fused path too (one workgroup stages up to 512 keys).  Ragged batches run PACKED
+    (no padding rows, round 3); PACK_BELOW_PERCENT = 0 forces the padded layout: same embeddings."""
     import torch
     from rag_uq_amd.embedders import NomicBertEmbedder
     torch.manual_seed(1)
@@ -1528,6 +1542,11 @@ def test_fused_nomic_bert_forward_matches_the_stock_module():
     assert a.shape == b.shape == (152, 768) and np.isfinite(a).all()
     cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
     assert cos.min() >= 0.9999, cos.min()
+    fused.fused.PACK_BELOW_PERCENT = 0
+    a_padded = fused.embed(texts)
+    fused.fused.PACK_BELOW_PERCENT = 97
+    cosp = (a * a_padded).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(a_padded, axis=1))
+    assert cosp.min() >= 0.99999, cosp.min()              # (the library picks its GEMM tiling by the row count: not bit-identical)
     assert float(np.abs(a - b).max()) <= 0.02 * float(np.abs(b).max())
     long_texts = ["y" * 400, "z" * 300, "w" * 512, "v" * 700]                               # (truncated at max_length = 512)
     la, lb = fused.embed(long_texts), stock.embed(long_texts)
