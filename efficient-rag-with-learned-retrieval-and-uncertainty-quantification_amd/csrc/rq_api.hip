@@ -271,6 +271,8 @@ static void scan8_reset_levels(rq_index* idx) {
     for (int c = 0; c < 2; ++c) {
         idx->scan8_level[c] = idx->scan8_split < 0 ? c : (idx->scan8_split ? 1 : 0);
         idx->scan8_checked[c] = idx->scan8_repaired[c] = 0;
+        idx->wide1_ok[c] = idx->wide1_off[c] = false;
+        idx->wide1_checked[c] = idx->wide1_repaired[c] = 0;
     }
     idx->calib_rows = 0;   // "scan8" = 1: the next search that brings the image up to date calibrates again
 }
@@ -358,6 +360,15 @@ extern "C" double rq_get_option(const rq_index* idx, const char* name) {
     if (s == "wide256_8") return idx->wide256_8;
     if (s == "scan8_row_err") return idx->x8_valid == idx->n && idx->x8 ? idx->max_e8 : -1.0;   // worst row's relative int8 error (-1: image not built)
     if (s == "scan8_suspended") return (idx->scan8_level[0] == 2 ? 1.0 : 0.0) + (idx->scan8_level[1] == 2 ? 2.0 : 0.0);   // bit 0: k <= 32, bit 1: larger k
+    if (s == "scan8_wide_one_image") {   // per class (units: k <= 32, tens: larger k): 1 = its calls of more than 64 queries scan ONE int8 image per query now
+        double r = 0;
+        for (int c = 0; c < 2; ++c) {
+            const int lvl = idx->scan8_level[c];
+            const bool on = idx->scan8 && idx->wide8 && (lvl == 0 || (lvl == 1 && !idx->wide1_off[c] && (idx->scan8 == 2 || idx->wide1_ok[c])));
+            r += (c ? 10.0 : 1.0) * (on ? 1 : 0);
+        }
+        return r;
+    }
     if (s == "scan8_level") return idx->scan8_level[0] + 10.0 * idx->scan8_level[1];   // per class: 0 one image, 1 two images, 2 fp16 scan   // too many repairs behind the int8 scan (rq_search_fixup_device)
     if (s == "scan8_calibrated_rows") return (double)idx->calib_rows;   // rows of the shard when the int8 ladder's start was last measured (0: never)
     // "scan8_calib_ms_<class><rung>" / "scan8_calib_unc_<class><rung>" (class 0: k <= 32, 1: larger; rung 0 one image, 1 two images,
@@ -515,6 +526,9 @@ static int scan8_calibrate(rq_index* idx, hipStream_t s) {
                 if ((level == 2 || unc_of[level] * 16 <= S) && ms_of[level] < 0.92f * ms_of[best]) best = level;
             idx->scan8_level[c] = best;
             idx->scan8_checked[c] = idx->scan8_repaired[c] = 0;
+            idx->wide1_ok[c] = unc_of[0] * 16 <= S;      // one image is eligible on the sample (whichever rung 64-query calls were given)
+            idx->wide1_off[c] = false;
+            idx->wide1_checked[c] = idx->wide1_repaired[c] = 0;
             for (int l = 0; l < 3; ++l) { idx->calib_ms[c][l] = ms_of[l]; idx->calib_unc[c][l] = unc_of[l]; }
         }
         idx->scan8_used = used0;      // (the calibration's own scans are not the caller's searches)
@@ -667,12 +681,17 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     const int kclass = k <= RQ_SCAN8_SMALL_K ? 0 : 1;
     // Calls of more than 64 queries: passes of 128 queries over the image (two 16-query groups per wave, rq_scan.hip I8 = 3) while
     // the class runs with one image per query and "wide8" is on; otherwise the fp16 passes of rq_scan_wide.hip.
-    const bool wide_ok = B <= 64 || (idx->wide8 && idx->wide_batch != 0 && idx->scan8_level[kclass] == 0);
+    // ... or while it runs with two images for its 64-query calls and one image is known to be good enough for the wide ones (wide1, rq_index.h)
+    auto wide_level_ok = [&]() {
+        const int lvl = idx->scan8_level[kclass];
+        return lvl == 0 || (lvl == 1 && !idx->wide1_off[kclass] && (idx->scan8 == 2 || idx->wide1_ok[kclass] || idx->calib_rows == 0));
+    };
+    const bool wide_ok = B <= 64 || (idx->wide8 && idx->wide_batch != 0 && wide_level_ok());
     if (allow8 && idx->scan8 && idx->scan8_level[kclass] < 2 && nb >= 0 && 2 * (int64_t)nb < nbins && wide_ok && !force_generic && idx->fast_tail &&
         k <= RQ_FAST_MAX_K && (idx->scan8 == 2 || (idx->n >= RQ_SCAN8_MIN_ROWS && k <= RQ_SCAN8_AUTO_MAX_K))) {
         if (int r = ensure_x8(idx, s)) return r;   // (may calibrate: the class's level is read again below)
         use8 = idx->x8 && idx->x8_valid == idx->n && idx->max_e8 <= RQ_SCAN8_MAX_ROW_ERR && idx->scan8_level[kclass] < 2 &&
-               (B <= 64 || idx->scan8_level[kclass] == 0);
+               (B <= 64 || (wide_level_ok() && (idx->scan8_level[kclass] == 0 || idx->scan8 == 2 || idx->wide1_ok[kclass])));
     }
     // Queries as ONE int8 image or as TWO (value + residual: the query's share of the bound vanishes, every corpus fragment
     // feeds two MFMAs).  Measured at 1M rows, fused loop: k = 10  132 us per batch with one image, 143-146 with two (the
@@ -681,7 +700,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     // more than 1 in 16 checked queries of a class needed repair, rq_search_fixup_device moves it one step along
     // one image -> two images -> fp16 scan (clustered corpus + random queries at k = 10: one image 19 of 64 queries repaired,
     // two images none, 245 us per batch against 275 with the fp16 scan).
-    const bool split8 = use8 && idx->scan8_level[kclass] == 1;
+    const bool split8 = use8 && idx->scan8_level[kclass] == 1 && B <= 64;      // (wide calls: one image)
     // tiny shards (fewer than two bins per wanted bin): the approximate pass cannot narrow anything down
     // ... and shards whose rows keep so much of their norm in fp16-subnormal elements that the fp16 scan's scores say nothing
     const bool exact = nb < 0 || 2 * (int64_t)nb >= nbins || (!use8 && idx->eps < 0 && scan_eps(idx, metric) > RQ_EPS_USELESS);
@@ -774,7 +793,7 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     signed char* const q8lo = fused ? cx.ring_q8lo[slot] : w.q8lo;
     float* const qeps8s = fused ? cx.ring_qeps8s[slot] : w.qeps8s;
     if (use8) idx->scan8_used++;
-    if (may_defer) idx->last_use8 = use8;   // (may_defer: the caller's own search, not a repair pass of rq_search_fixup_device)
+    if (may_defer) { idx->last_use8 = use8; idx->last_wide1 = use8 && B > 64 && idx->scan8_level[kclass] == 1; }   // (may_defer: the caller's own search, not a repair pass of rq_search_fixup_device)
     // ... unless the previous launch of this stream has already prepared exactly these queries (rq_search_hint_next_device)
     const bool prepared = fused && cx.prepped_q == d_q && cx.prepped_B == B && cx.prepped_slot == slot;
     cx.prepped_q = nullptr;
@@ -1023,6 +1042,14 @@ static void scan8_account(rq_index* idx, int k, int checked, int repaired) {
     if (!idx->last_use8 || !idx->x8 || !idx->scan8) return;
     const int kclass = k <= RQ_SCAN8_SMALL_K ? 0 : 1;
     if (idx->scan8_level[kclass] >= 2) return;
+    if (idx->last_wide1) {       // a wide call on one image in a two-image class: its repairs decide about the wide calls only
+        idx->wide1_checked[kclass] += checked; idx->wide1_repaired[kclass] += repaired;
+        if (idx->wide1_checked[kclass] >= 256) {
+            if (idx->wide1_repaired[kclass] * 16 > idx->wide1_checked[kclass]) idx->wide1_off[kclass] = true;
+            idx->wide1_checked[kclass] = idx->wide1_repaired[kclass] = 0;
+        }
+        return;
+    }
     idx->scan8_checked[kclass] += checked; idx->scan8_repaired[kclass] += repaired;
     if (idx->scan8_checked[kclass] >= 256) {
         if (idx->scan8_repaired[kclass] * 16 > idx->scan8_checked[kclass]) idx->scan8_level[kclass]++;

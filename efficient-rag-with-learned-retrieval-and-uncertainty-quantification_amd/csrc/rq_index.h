@@ -127,6 +127,11 @@ struct rq_index {
     int calib_unc[2][3] = {{0, 0, 0}, {0, 0, 0}};    // ... and its uncertified queries
     bool wg_auto = true;           // scan workgroups per CU by the library's rule (option "wg_per_cu" pins it)
     bool last_use8 = false;        // the caller's last search scanned the int8 image (what rq_search_fixup_device's repairs are counted against)
+    // Calls of more than 64 queries in a class whose own rung is "two images" (k > 32 by default): the 256- / 128-query passes exist for ONE image only,
+    // and one image there beats the fp16 wide passes (1M rows, 500 queries, k = 100: 740 against 944 us).  Allowed when the image-build measurement found the
+    // one-image rung eligible for the class (or the image is forced, scan8 = 2); given up -- for wide calls only -- when more than 1 in 16 of their queries needed repair.
+    bool wide1_ok[2] = {false, false}, wide1_off[2] = {false, false}, last_wide1 = false;
+    int64_t wide1_checked[2] = {0, 0}, wide1_repaired[2] = {0, 0};
     int64_t repaired_total = 0;    // queries that came back uncertified and were repaired (any rung of the repair ladder)
     int64_t hints_used = 0;        // rq_search_hint_next_device: searches that skipped their preparation launch
     uint64_t scan_seq = 0;         // scan launches seen while profile = 1 (every profile_stride-th one is timed)

@@ -161,6 +161,8 @@ int rq_merge_keys_device(const uint64_t* d_keys_in, int n_per_query, int B, int 
  *   fastest rung that certifies wins; "scan8_calibrated_rows", "scan8_calib_ms_<class><rung>", "scan8_calib_unc_<class><rung>" report it).
  * Read-only: "repaired_queries" (queries that came back uncertified and were repaired, all rungs of the ladder), "scan8_used" (searches that scanned the int8 image), "scan8_row_err" (worst row's relative int8 error, -1 = image
  * not built), "scan8_level" (ladder position: class k <= 32 + 10 * class of larger k; 0 one image, 1 two images, 2 fp16 scan),
+ * "scan8_wide_one_image" (same encoding: 1 = calls of more than 64 queries of that class scan ONE int8 image per query -- also in a class whose 64-query calls
+ *   run on two images, when the image-build measurement found one image eligible; given up for the wide calls alone after too many repairs),
  * "scan8_suspended" (bit 0 / 1: that class is back at the fp16 scan), "hints_used" (searches that found their queries prepared, see rq_search_hint_next_device), "max_row_norm", "max_sub_rel" / "max_sub_abs" (largest share of a stored row that sits in fp16-subnormal elements,
  * which the matrix cores flush), "eps_cosine" / "eps_ip" (the certificate's bound including that term). */
 int rq_set_option(rq_index* idx, const char* name, double value);

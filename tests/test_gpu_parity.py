@@ -1599,7 +1599,11 @@ def test_int8_wide_passes_match_oracle():
     with pytest.raises(nat.RqError):
         idx.set_option("wide256_8", 7)
     before = int(idx.get_option("scan8_used"))
-    _check(idx, x16, orc.synthetic_queries(130, 768, seed=4), 100)  # k > 32: two-image class -> the fp16 wide passes
+    assert int(idx.get_option("scan8_level")) == 10 and int(idx.get_option("scan8_wide_one_image")) == 11
+    _check(idx, x16, orc.synthetic_queries(130, 768, seed=4), 100)  # k > 32: the class's 64-query calls run on two images, its WIDE calls on one (round 3)
+    _check(idx, x16, q600[:333], 50)                                 # 256 + 128 at k = 50
+    assert int(idx.get_option("scan8_used")) == before + 2 and int(idx.get_option("scan8_level")) == 10
+    before += 2
     idx.set_option("wide8", 0)
     _check(idx, x16, orc.synthetic_queries(130, 768, seed=5), 10)   # switched off -> the fp16 wide passes
     _check(idx, x16, q600[:448], 10)                                  # fp16 256 + 128 + 64: the 64-query remainder on its own (two-per-CU) grid
@@ -1650,6 +1654,43 @@ def test_int8_ladder_counts_clean_calls_too():
             idx.search(dirty[i:i + 1], 10)
     assert int(idx.get_option("scan8_level")) % 10 >= 1
     _check(idx, x16, dirty, 10)
+    idx.close()
+
+
+def test_wide_calls_of_a_two_image_class_scan_one_image_and_give_it_up_on_their_own():
+    """Round 3: calls of more than 64 queries at k > 32 scan ONE int8 image per query (the 128- / 256-query passes exist for one image only)
+    although the class's 64-query calls run on two.  Their repairs are counted in a window of their own: more than 1 in 16 switches the WIDE
+    calls of the class back to the fp16 passes and leaves the class's ladder position alone.  Results equal the oracle throughout."""
+    xg = orc.synthetic_corpus(30_000, 768, seed=61)
+    xc = orc.synthetic_corpus(60_000, 768, seed=62, clustered=True)     # on-topic queries into tight clusters need the repair ladder on one image
+    x16 = np.concatenate([xg, xc], 0)
+    idx = nat.NativeIndex(768, 0)
+    idx.add_f16(x16)
+    idx.set_option("scan8", 2)
+    assert int(idx.get_option("scan8_level")) == 10 and int(idx.get_option("scan8_wide_one_image")) == 11
+    clean = xg[::200][:128].astype(np.float32) + 0.2 * orc.synthetic_queries(128, 768, seed=63)
+    dirty = xc[5::461][:128].astype(np.float32)
+    # clean wide calls: one image, nothing repaired, the switch stays on
+    used = int(idx.get_option("scan8_used")); rep0 = int(idx.get_option("repaired_queries"))
+    for _ in range(3):
+        _check(idx, x16, clean, 50)
+    assert int(idx.get_option("scan8_used")) == used + 3 and int(idx.get_option("scan8_wide_one_image")) == 11
+    clean_repairs = int(idx.get_option("repaired_queries")) - rep0
+    assert clean_repairs * 16 <= 3 * 128, clean_repairs
+    # dirty wide calls: repaired exactly, and after a window of 256 checked queries the wide calls of the class leave the image
+    rep0 = int(idx.get_option("repaired_queries"))
+    for _ in range(2):
+        _check(idx, x16, dirty, 50)
+    dirty_repairs = int(idx.get_option("repaired_queries")) - rep0
+    assert dirty_repairs * 16 > 256, f"expected the on-topic queries to need repairs on one image, got {dirty_repairs} of 256"
+    assert int(idx.get_option("scan8_wide_one_image")) == 1           # class k > 32: off for wide calls; class k <= 32 untouched
+    assert int(idx.get_option("scan8_level")) == 10                    # ... and the ladder of its 64-query calls was not moved by them
+    used = int(idx.get_option("scan8_used"))
+    _check(idx, x16, clean, 50)                                        # wide, k > 32: the fp16 passes now
+    assert int(idx.get_option("scan8_used")) == used
+    _check(idx, x16, clean[:64], 50)                                   # 64 queries: still the image (two per query)
+    _check(idx, x16, clean, 10)                                        # wide, k <= 32: still one image
+    assert int(idx.get_option("scan8_used")) == used + 2
     idx.close()
 
 
