@@ -364,7 +364,7 @@ extern "C" double rq_get_option(const rq_index* idx, const char* name) {
         double r = 0;
         for (int c = 0; c < 2; ++c) {
             const int lvl = idx->scan8_level[c];
-            const bool on = idx->scan8 && idx->wide8 && (lvl == 0 || (lvl == 1 && !idx->wide1_off[c] && (idx->scan8 == 2 || idx->wide1_ok[c])));
+            const bool on = idx->scan8 && idx->wide8 && (lvl == 0 || (lvl == 1 && idx->scan8_split < 0 && !idx->wide1_off[c] && (idx->scan8 == 2 || idx->wide1_ok[c])));
             r += (c ? 10.0 : 1.0) * (on ? 1 : 0);
         }
         return r;
@@ -684,7 +684,8 @@ static int run_pipeline(rq_index* idx, const float* d_q, int B, int k, int metri
     // ... or while it runs with two images for its 64-query calls and one image is known to be good enough for the wide ones (wide1, rq_index.h)
     auto wide_level_ok = [&]() {
         const int lvl = idx->scan8_level[kclass];
-        return lvl == 0 || (lvl == 1 && !idx->wide1_off[kclass] && (idx->scan8 == 2 || idx->wide1_ok[kclass] || idx->calib_rows == 0));
+        // (not under an explicit "scan8_split" = 1: the caller asked for two images everywhere, which no wide pass offers)
+        return lvl == 0 || (lvl == 1 && idx->scan8_split < 0 && !idx->wide1_off[kclass] && (idx->scan8 == 2 || idx->wide1_ok[kclass] || idx->calib_rows == 0));
     };
     const bool wide_ok = B <= 64 || (idx->wide8 && idx->wide_batch != 0 && wide_level_ok());
     if (allow8 && idx->scan8 && idx->scan8_level[kclass] < 2 && nb >= 0 && 2 * (int64_t)nb < nbins && wide_ok && !force_generic && idx->fast_tail &&
