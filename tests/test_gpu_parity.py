@@ -1661,36 +1661,38 @@ def test_wide_calls_of_a_two_image_class_scan_one_image_and_give_it_up_on_their_
     """Round 3: calls of more than 64 queries at k > 32 scan ONE int8 image per query (the 128- / 256-query passes exist for one image only)
     although the class's 64-query calls run on two.  Their repairs are counted in a window of their own: more than 1 in 16 switches the WIDE
     calls of the class back to the fp16 passes and leaves the class's ladder position alone.  Results equal the oracle throughout."""
-    xg = orc.synthetic_corpus(30_000, 768, seed=61)
-    xc = orc.synthetic_corpus(60_000, 768, seed=62, clustered=True)     # on-topic queries into tight clusters need the repair ladder on one image
-    x16 = np.concatenate([xg, xc], 0)
+    # (a) Gaussian rows: wide calls at k = 50 / 100 stay on the image, nothing to repair
+    xg = orc.synthetic_corpus(90_000, 768, seed=61)
+    idx = nat.NativeIndex(768, 0)
+    idx.add_f16(xg)
+    idx.set_option("scan8", 2)
+    assert int(idx.get_option("scan8_level")) == 10 and int(idx.get_option("scan8_wide_one_image")) == 11
+    used = int(idx.get_option("scan8_used")); rep0 = int(idx.get_option("repaired_queries"))
+    for B, k in ((128, 50), (300, 100), (200, 50)):
+        _check(idx, xg, orc.synthetic_queries(B, 768, seed=B + k), k)
+    assert int(idx.get_option("scan8_used")) == used + 3 and int(idx.get_option("scan8_wide_one_image")) == 11
+    assert int(idx.get_option("repaired_queries")) == rep0
+    idx.close()
+    # (b) a third Gaussian, two thirds in 64 tight clusters: top-50 lists come out of one cluster, hundreds of rows sit inside the one-image bound
+    xc = orc.synthetic_corpus(60_000, 768, seed=62, clustered=True)
+    x16 = np.concatenate([xg[:30_000], xc], 0)
     idx = nat.NativeIndex(768, 0)
     idx.add_f16(x16)
     idx.set_option("scan8", 2)
-    assert int(idx.get_option("scan8_level")) == 10 and int(idx.get_option("scan8_wide_one_image")) == 11
-    clean = xg[::200][:128].astype(np.float32) + 0.2 * orc.synthetic_queries(128, 768, seed=63)
-    dirty = xc[5::461][:128].astype(np.float32)
-    # clean wide calls: one image, nothing repaired, the switch stays on
-    used = int(idx.get_option("scan8_used")); rep0 = int(idx.get_option("repaired_queries"))
-    for _ in range(3):
-        _check(idx, x16, clean, 50)
-    assert int(idx.get_option("scan8_used")) == used + 3 and int(idx.get_option("scan8_wide_one_image")) == 11
-    clean_repairs = int(idx.get_option("repaired_queries")) - rep0
-    assert clean_repairs * 16 <= 3 * 128, clean_repairs
-    # dirty wide calls: repaired exactly, and after a window of 256 checked queries the wide calls of the class leave the image
-    rep0 = int(idx.get_option("repaired_queries"))
-    for _ in range(2):
-        _check(idx, x16, dirty, 50)
-    dirty_repairs = int(idx.get_option("repaired_queries")) - rep0
-    assert dirty_repairs * 16 > 256, f"expected the on-topic queries to need repairs on one image, got {dirty_repairs} of 256"
+    q = orc.synthetic_queries(128, 768, seed=63)
+    rep0 = int(idx.get_option("repaired_queries")); used = int(idx.get_option("scan8_used"))
+    for _ in range(2):                                                 # one window of 256 checked queries
+        _check(idx, x16, q, 50)
+    repairs = int(idx.get_option("repaired_queries")) - rep0
+    assert int(idx.get_option("scan8_used")) == used + 2
+    assert repairs * 16 > 256, f"expected top-50 lists inside tight clusters to need repairs on one image, got {repairs} of 256"
     assert int(idx.get_option("scan8_wide_one_image")) == 1           # class k > 32: off for wide calls; class k <= 32 untouched
     assert int(idx.get_option("scan8_level")) == 10                    # ... and the ladder of its 64-query calls was not moved by them
     used = int(idx.get_option("scan8_used"))
-    _check(idx, x16, clean, 50)                                        # wide, k > 32: the fp16 passes now
+    _check(idx, x16, q, 50)                                            # wide, k > 32: the fp16 passes now
     assert int(idx.get_option("scan8_used")) == used
-    _check(idx, x16, clean[:64], 50)                                   # 64 queries: still the image (two per query)
-    _check(idx, x16, clean, 10)                                        # wide, k <= 32: still one image
-    assert int(idx.get_option("scan8_used")) == used + 2
+    _check(idx, x16, q[:64], 50)                                       # 64 queries: still the image (two per query)
+    assert int(idx.get_option("scan8_used")) == used + 1
     idx.close()
 
 
