@@ -288,6 +288,10 @@ def main() -> None:
             idx.set_option("scan8", SCAN_OPT[scan])
             idx.set_option("profile", 0)
             self.preheat()
+            if use_comm:      # the communicator and the all-gather path are warm before the timed region whatever --warmup is (a run with --warmup 0
+                with torch.cuda.stream(comm_stream):      # would otherwise pay RCCL's lazy set-up inside it)
+                    all_gather_keys(self.gathered[0], self.ring[0])
+                comm_stream.synchronize()
             self.run_steps(warmup)
             self.flush()
             self.finish()        # the end-of-run sequence once before the timed region: the first numpy reduction / nonzero of a process cost
