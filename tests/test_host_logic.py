@@ -362,6 +362,7 @@ def test_bm25_batch_equals_per_query_equals_oracle_with_ties():
     b = si.BM25Index()
     b.add_documents([si.Document(id=i, text=t) for i, t in zip(ids, texts)])
     queries = [" ".join(rng.choice(vocab, size=5)) for _ in range(40)] + [texts[7], "w3 w3 w3 unknownword", "nothing known here", ""]
+    b.SINGLE_NATIVE_AFTER = None                                # `search` on its own (numpy) path: the reference the batch forms are held against
     for k in (1, 10, 400):
         per_query = [b.search(q, k) for q in queries]
         assert b.search_batch(queries, k) == per_query
@@ -377,6 +378,22 @@ def test_bm25_batch_equals_per_query_equals_oracle_with_ties():
     b.add_documents([si.Document(id="new", text=texts[7])])
     assert b.search_batch([texts[7]], 3) == [b.search(texts[7], 3)] and b.search(texts[7], 1)[0][0] == "new"
     assert si.BM25Index().search_batch(["x"], 3) == [[]]
+    # one query per call (the reference's evaluation loop): after a few searches over an unchanged corpus `search` itself goes through the
+    # batch scorer -- same lists -- and an add sends it back to its own path until the corpus has been stable again
+    want = [b.search(q, 10) for q in queries]
+    b.SINGLE_NATIVE_AFTER = 4
+    b._drop_csr()
+    for i, q in enumerate(queries[:4]):
+        assert b.search(q, 10) == want[i] and "_csr_cache" not in b.__dict__
+    got = [b.search(q, 10) for q in queries]
+    assert got == want
+    from rag_uq_amd import _native as nat_
+    assert ("_csr_cache" in b.__dict__) == nat_.bm25_available()
+    b.add_documents([si.Document(id="newer", text="w1 w2")])
+    n_before = b.__dict__.get("_csr_cache", {}).get("n_docs")
+    assert b.search("w1 w2", 1)[0][0] == "newer"
+    assert b.__dict__.get("_csr_cache", {}).get("n_docs") == n_before          # (stale arrays were not rebuilt for one search)
+    assert b.search("w1 w2", 0) == [] and b.search("", 5) == []
 
 
 class _StubNative:

@@ -24,5 +24,9 @@ t0 = time.perf_counter(); bm._csr(); print(f"CSR arrays + contributions ({bm._cs
 for thr in ([int(sys.argv[2])] if len(sys.argv) > 2 else [1, 4, 16, 0]):
     t0 = time.perf_counter(); res = bm.search_batch(questions, 100, n_threads=thr); dt = time.perf_counter() - t0
     print(f"search_batch 500 questions top-100, n_threads={thr or 'auto'}: {dt * 1e3:.1f} ms ({500 / dt:.0f} questions/s)", flush=True)
+bm.SINGLE_NATIVE_AFTER = None       # BM25Index.search on its own (numpy) path
 t0 = time.perf_counter(); ref = [bm.search(q, 100) for q in questions[:40]]; dt = (time.perf_counter() - t0) / 40
+bm.SINGLE_NATIVE_AFTER = 4          # the default: one-query searches over an unchanged corpus go through the batch scorer's arrays (round 3)
+t0 = time.perf_counter(); ref1 = [bm.search(q, 100) for q in questions[:200]]; dt1 = (time.perf_counter() - t0) / 200
+print(f"one query per call through the batch scorer: {dt1 * 1e3:.2f} ms per question; identical to the batch: {ref1 == res[:200]}", flush=True)
 print(f"per-query search: {dt * 1e3:.1f} ms per question; identical to the batch: {ref == res[:40]}; answer in top-100: {np.mean([f'p{a}' in [d for d, _ in r] for a, r in zip(ans, res)]):.3f}", flush=True)
