@@ -124,31 +124,47 @@ class FusedNomicBertForward:
                 g1=lyr.post_attention_layernorm.weight.contiguous(), b1=lyr.post_attention_layernorm.bias.contiguous(),
                 g2=lyr.post_mlp_layernorm.weight.contiguous(), b2=lyr.post_mlp_layernorm.bias.contiguous()))
 
-    def usable(self, ids, mask) -> bool:
+    def usable(self, ids, mask, lengths_host=None) -> bool:
+        """lengths_host: the sequence lengths as a host array when the caller KNOWS the batch is right-padded (the tokenizer built the
+        mask on the host): the device-side check of the mask -- and its synchronisation -- is skipped."""
         torch = self.torch
         if not (self.ok and ids.is_cuda and ids.shape[1] <= self.MAX_SEQ and self.layers and self.layers[0]["wqkv"].dtype == torch.float16):
             return False
+        if lengths_host is not None:
+            return True
         lengths = mask.sum(1)
         return bool((mask == (torch.arange(mask.shape[1], device=mask.device)[None, :] < lengths[:, None])).all())   # valid tokens first
 
-    def __call__(self, ids, mask):
-        """[B][L] token ids + right-padded attention mask -> [B][hidden] fp32 mean-pooled embeddings (device tensor)."""
+    def __call__(self, ids, mask, lengths_host=None):
+        """[B][L] token ids + right-padded attention mask -> [B][hidden] fp32 mean-pooled embeddings (device tensor).  lengths_host
+        (numpy, the same lengths the mask encodes): nothing is read back from the device before the first kernel."""
         torch, nat = self.torch, self.nat
         F = torch.nn.functional
         B, L = ids.shape
         H = self.hidden
         st = torch.cuda.current_stream(ids.device).cuda_stream
-        lengths = mask.sum(1).to(torch.int32).contiguous()
+        if lengths_host is not None:
+            lens_np = np.ascontiguousarray(lengths_host, dtype=np.int32)
+            lengths = torch.from_numpy(lens_np).to(ids.device)
+            total = int(lens_np.sum())
+        else:
+            lengths = mask.sum(1).to(torch.int32).contiguous()
+            lens_np = None
+            total = int(lengths.sum())
         pos = torch.arange(L, device=ids.device)[None, :]
         # Ragged batches run PACKED: the token rows of all sequences back to back (no padding rows), an offset table instead of the
         # lengths -- GEMMs, LayerNorm and SwiGLU then work on sum(lengths) rows instead of B * longest.  (Batches that are all but full
         # keep the padded layout: the gather below is not free.)
-        total = int(lengths.sum())
         packed = total * 100 <= B * L * self.PACK_BELOW_PERCENT
         if packed:
             keep = mask.bool()
-            offs = torch.zeros((B + 1,), device=ids.device, dtype=torch.int32)
-            offs[1:] = torch.cumsum(lengths, 0)
+            if lens_np is not None:
+                offs_np = np.zeros((B + 1,), np.int32)
+                np.cumsum(lens_np, out=offs_np[1:])
+                offs = torch.from_numpy(offs_np).to(ids.device)
+            else:
+                offs = torch.zeros((B + 1,), device=ids.device, dtype=torch.int32)
+                offs[1:] = torch.cumsum(lengths, 0)
             T = total
             h = self.emb(input_ids=ids[keep][None, :], position_ids=pos.expand(B, L)[keep][None, :]).reshape(T, H).contiguous()
         else:
@@ -236,7 +252,10 @@ class NomicBertEmbedder:
         torch = self.torch
         if self.tokenizer is not None:
             enc = self.tokenizer(list(texts), padding=True, truncation=True, max_length=self.max_length, return_tensors="pt")
-            return enc["input_ids"].to(self.device), enc["attention_mask"].to(self.device)
+            m = enc["attention_mask"]
+            lens = m.sum(1)
+            right_padded = bool((m == (torch.arange(m.shape[1])[None, :] < lens[:, None])).all())       # (on the host: the tokenizer's own tensors)
+            return enc["input_ids"].to(self.device), m.to(self.device), (lens.numpy().astype(np.int32) if right_padded else None)
         # stand-in: utf-8 bytes shifted into the vocabulary (random-init smoke path only)
         raw = [np.frombuffer(t.encode()[: self.max_length], dtype=np.uint8) for t in texts]
         L = max(max((len(r) for r in raw), default=1), 1)
@@ -248,7 +267,7 @@ class NomicBertEmbedder:
             else:
                 ids[i, : len(r)] = r.astype(np.int64) % (self.vocab - 10) + 5
                 mask[i, : len(r)] = 1
-        return torch.from_numpy(ids).to(self.device), torch.from_numpy(mask).to(self.device)
+        return torch.from_numpy(ids).to(self.device), torch.from_numpy(mask).to(self.device), mask.sum(1).astype(np.int32)
 
     def embed_device(self, texts: Sequence[str]):
         """[len(texts)][dim] fp32 embeddings as ONE tensor on the embedder's device, rows in the caller's order (what
@@ -265,9 +284,9 @@ class NomicBertEmbedder:
         with torch.inference_mode():
             for lo in range(0, len(order), self.batch_size):
                 sel = order[lo: lo + self.batch_size]
-                ids, mask = self._tokenize([texts[i] for i in sel])
-                if self.fused is not None and self.fused.usable(ids, mask):
-                    v = self.fused(ids, mask)
+                ids, mask, lens_host = self._tokenize([texts[i] for i in sel])
+                if self.fused is not None and self.fused.usable(ids, mask, lens_host):
+                    v = self.fused(ids, mask, lens_host)
                 else:
                     h = self.model(input_ids=ids, attention_mask=mask).last_hidden_state.float()
                     m = mask.unsqueeze(-1).float()

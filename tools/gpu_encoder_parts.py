@@ -13,7 +13,7 @@ def t(fn, reps=10):
     for _ in range(reps): r = fn()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / reps * 1e3, r
-ms_tok, (ids, mask) = t(lambda: emb._tokenize(queries))
+ms_tok, (ids, mask, _lens) = t(lambda: emb._tokenize(queries))
 print(f"tokenise (host + H2D): {ms_tok:.2f} ms   ids {tuple(ids.shape)}")
 with torch.inference_mode():
     ms_fwd, out = t(lambda: emb.model(input_ids=ids, attention_mask=mask).last_hidden_state)
