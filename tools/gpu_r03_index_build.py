@@ -12,7 +12,7 @@ emb = NomicBertEmbedder(random_init=True, num_layers=12, device="cuda:0", dtype=
 rng = np.random.default_rng(3)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000
 lens = rng.integers(40, 401, size=n)
-docs = [si.Document(id=f"p{i}", text="".join(chr(97 + (i * 7 + j * 3) % 26) if j % 6 else " " for j in range(int(L))), title=f"t{i}") for i, L in enumerate(lens)]
+docs = [si.Document(id=f"p{i}", text=f"doc{i} " + "".join(chr(97 + (i * 7 + j * 3) % 26) if j % 6 else " " for j in range(int(L))), title=f"t{i}") for i, L in enumerate(lens)]
 for bs in (100, 1000):
     tmp = tempfile.mkdtemp()
     r = si.HybridRetriever(bm25_persist_path=os.path.join(tmp, "bm25.pkl"), chroma_persist_path=os.path.join(tmp, "c"),
@@ -34,3 +34,4 @@ for bs in (100, 1000):
     print(f"batches of {bs:4d}: {m} passages in {dt:.2f} s = {m / dt:7.0f} passages/s  (embedding {t_emb:.2f} s = {m / t_emb:7.0f} passages/s; BM25 + append + persistence {dt - t_emb:.2f} s)", flush=True)
     hit = r.hybrid_search(docs[777].text, top_k=3)
     print("   query = passage 777 ->", [x.doc_id for x in hit][:3], "dense rows", len(r.dense_index), flush=True)
+    assert hit[0].doc_id == "p777"
