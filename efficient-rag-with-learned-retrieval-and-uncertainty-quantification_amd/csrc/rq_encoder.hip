@@ -122,12 +122,23 @@ __global__ __launch_bounds__(64 * NW) void rq_nb_attention_kernel(const _Float16
         *(rq_half8*)(Sk + r * NB_KSTRIDE + 8 * j) = olo;
         *(rq_half8*)(Sk + r * NB_KSTRIDE + 32 + 8 * j) = ohi;
     }
-    for (int i = tid; i < nk * 8; i += 64 * NW) {
-        const int r = i >> 3, j = i & 7;
-        rq_half8 v = zero8;
-        if (r < n) v = *(const rq_half8*)(qkv + (row0 + r) * ld + 2 * H + head * NB_HEAD_DIM + 8 * j);
+    // V^T: a thread takes 4 consecutive keys x 8 dims -- four 16-byte loads, eight 8-byte LDS writes; the lanes of a wave hold consecutive
+    // key groups of one dim block, so every write instruction covers a linear address range (the 2-byte scatter of round 2's form cost
+    // 61 M bank-conflict cycles per launch at 512 tokens, a fifth of the kernel's LDS time: profiles/r03_attention512_pmc.json)
+    {
+        const int ng = nk >> 2;                             // key groups (nk is a multiple of 32)
+        for (int i = tid; i < ng * 8; i += 64 * NW) {
+            const int r4 = i % ng, j = i / ng;
+            rq_half8 v[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) Svt[(8 * j + e) * vstride + r] = v[e];
+            for (int u = 0; u < 4; ++u) {
+                const int r = 4 * r4 + u;
+                v[u] = zero8;
+                if (r < n) v[u] = *(const rq_half8*)(qkv + (row0 + r) * ld + 2 * H + head * NB_HEAD_DIM + 8 * j);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) *(rq_half4*)(Svt + (8 * j + e) * vstride + 4 * r4) = rq_half4{v[0][e], v[1][e], v[2][e], v[3][e]};
+        }
     }
     __syncthreads();                                        // the only barrier: K and V^T are read-only from here on
     const int r16 = lane & 15, kg = lane >> 4;
