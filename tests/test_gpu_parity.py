@@ -1616,8 +1616,8 @@ def test_int8_wide_passes_match_oracle():
 def test_int8_ladder_counts_clean_calls_too():
     """a server answering ONE query per call (reference DenseIndex.search, streaming_index.py:338-370) used to report only
     its failing calls to the int8 ladder (rq_search_end's clean branch counted nothing), so repaired / checked was always >= 1 and 256
-    repaired queries IN TOTAL moved the class to the fp16 scan for good.  Now every checked query counts: 7 000 clean one-query calls
-    with 280 queries that need repair among them (4 %, below the 1-in-16 rule) leave the level alone, results stay exact."""
+    repaired queries IN TOTAL moved the class to the fp16 scan for good.  Now every checked query counts: 3 000 clean one-query calls
+    with 120 queries that need repair among them (4 %, below the 1-in-16 rule; 12 windows of 256) leave the level alone, results stay exact."""
     xg = orc.synthetic_corpus(30_000, 768, seed=61)
     xc = orc.synthetic_corpus(60_000, 768, seed=62, clustered=True)     # 64 tight centroids of ~940 rows: inside one, the k-th approximate
     x16 = np.concatenate([xg, xc], 0)                                   # score overestimates the exact one by more than the threshold's slack
@@ -1640,16 +1640,16 @@ def test_int8_ladder_counts_clean_calls_too():
     base = int(idx.get_option("repaired_queries"))
     idx.set_option("scan8", 2)                            # start over: levels and windows
     assert idx.get_option("scan8_level") == 10.0
-    for rep in range(70):
+    for rep in range(30):                                 # (a repaired call costs tens of ms -- the ladder's rungs: the counts are what the windows need)
         for i in range(100):
             idx.search(clean[i:i + 1], 10)
         for i in range(4):
             idx.search(dirty[i:i + 1], 10)
     assert idx.get_option("scan8_level") == 10.0, "4 % repaired queries must not move the k <= 32 class off the one-image scan"
-    assert int(idx.get_option("repaired_queries")) == base + 280          # (only the dirty ones were repaired, every time)
+    assert int(idx.get_option("repaired_queries")) == base + 120          # (only the dirty ones were repaired, every time)
     _check(idx, x16, clean[:64], 10)
-    # ... while a stream of nothing but failing one-query calls still escalates
-    for rep in range(150):
+    # ... while a stream of nothing but failing one-query calls still escalates (one full window of 256 is enough)
+    for rep in range(70):
         for i in range(4):
             idx.search(dirty[i:i + 1], 10)
     assert int(idx.get_option("scan8_level")) % 10 >= 1
