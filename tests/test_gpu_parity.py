@@ -1628,7 +1628,7 @@ def test_int8_ladder_counts_clean_calls_too():
     def repaired_by(qv):
         idx.set_option("scan8", 2)                        # (fresh ladder windows: the probing itself must not move the level)
         before = int(idx.get_option("repaired_queries"))
-        _check(idx, x16, qv[None, :], 10)
+        idx.search(qv[None, :], 10)                       # (exactness of both kinds is checked against the oracle below, in two batched calls)
         return int(idx.get_option("repaired_queries")) - before
     # queries that need the repair ladder (stored rows of the clusters) and queries that never do (near Gaussian rows), picked by trying
     cand_dirty = xc[5::461][:96].astype(np.float32)
@@ -1637,6 +1637,8 @@ def test_int8_ladder_counts_clean_calls_too():
     cand_clean = xg[::200][:150].astype(np.float32) + 0.2 * orc.synthetic_queries(150, 768, seed=63)
     clean = np.stack([v for v in cand_clean if repaired_by(v) == 0][:100])
     assert clean.shape[0] == 100
+    idx.set_option("scan8", 2)
+    _check(idx, x16, np.concatenate([dirty, clean[:60]], 0), 10)
     base = int(idx.get_option("repaired_queries"))
     idx.set_option("scan8", 2)                            # start over: levels and windows
     assert idx.get_option("scan8_level") == 10.0
